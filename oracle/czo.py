@@ -1,0 +1,367 @@
+"""ctypes binding of the CPU oracle (oracle/cz_oracle.h).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; nothing under
+candlezip_amd/ does.  The shared object is built on demand with oracle/Makefile (gcc).
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libcz_oracle.so")
+AC_CDF_TOTAL = 1 << 30
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h")) or f == "Makefile"]
+    stale = not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B"], check=True, stdout=subprocess.DEVNULL)
+    return _SO
+
+
+class LlamaConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in "vocab d_model n_layers n_heads n_kv_heads d_ffn max_pos".split()] + \
+               [("rope_theta", C.c_float), ("rms_eps", C.c_float)]
+
+
+class Rwkv7Config(C.Structure):
+    _fields_ = [(n, C.c_int) for n in "vocab hidden n_layers head_dim d_ffn a_rank decay_rank v_rank gate_rank".split()] + \
+               [("norm_eps", C.c_float)]
+
+
+class Header(C.Structure):
+    _fields_ = [("bos_token_id", C.c_uint32), ("token_count", C.c_uint64), ("orig_len_bytes", C.c_uint64),
+                ("model_hash16", C.c_uint8 * 16), ("tokenizer_hash16", C.c_uint8 * 16), ("orig_hash16", C.c_uint8 * 16),
+                ("reserved_flags", C.c_uint32), ("context_window", C.c_uint32), ("vocab_size", C.c_uint32),
+                ("model_file_repr_len", C.c_uint32), ("reprime_interval", C.c_uint32)]
+
+
+class Encoder(C.Structure):
+    _fields_ = [("low", C.c_uint64), ("high", C.c_uint64), ("carry_run", C.c_uint64), ("bit_buffer", C.c_uint8),
+                ("bit_count", C.c_uint8), ("out", C.c_void_p), ("out_len", C.c_size_t), ("out_cap", C.c_size_t),
+                ("zero_width", C.c_uint64)]
+
+
+class Decoder(C.Structure):
+    _fields_ = [("low", C.c_uint64), ("high", C.c_uint64), ("code", C.c_uint64), ("inp", C.c_void_p),
+                ("in_len", C.c_size_t), ("byte_pos", C.c_size_t), ("bit_pos", C.c_uint8)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_SO)
+    vp, sz, u32, u64, f32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_float
+    sig = {
+        "czo_expf": (f32, [f32]), "czo_logf": (f32, [f32]), "czo_tanhf": (f32, [f32]),
+        "czo_dot": (f32, [vp, vp, C.c_int]), "czo_sum": (f32, [vp, C.c_int]),
+        "czo_softmax_pdf": (None, [vp, sz, vp]), "czo_softmax_pdf_floor": (None, [vp, sz, C.c_double, vp]),
+        "czo_combined_pdf_with_literals": (None, [vp, sz, vp]), "czo_quantize_pdf_to_cdf": (None, [vp, sz, vp]),
+        "czo_logits_to_cdf_smollm": (None, [vp, sz, vp]), "czo_logits_to_cdf_rwkv": (None, [vp, sz, vp]),
+        "czo_ac_p_min": (C.c_double, []),
+        "czo_enc_init": (None, [vp]), "czo_enc_encode_counts": (None, [vp, u64, u64, u64]),
+        "czo_enc_finish": (sz, [vp, vp]), "czo_enc_free": (None, [vp]),
+        "czo_dec_init": (None, [vp, vp, sz]), "czo_dec_decode_symbol_counts": (u32, [vp, vp, sz, u32]),
+        "czo_write_header_v2": (sz, [vp, vp, vp, sz]), "czo_read_header_v2": (sz, [vp, sz, vp, vp]),
+        "czo_write_var_u64": (sz, [u64, vp]), "czo_read_var_u64": (sz, [vp, sz, vp]),
+        "czo_flags_pack": (u32, [C.c_int, C.c_int, C.c_int, u32]),
+        "czo_llama_config_smollm2_135m": (None, [vp]),
+        "czo_smollm_new_synthetic": (vp, [vp, u64, f32]), "czo_smollm_free": (None, [vp]),
+        "czo_smollm_vocab": (sz, [vp]), "czo_smollm_index_pos": (sz, [vp]),
+        "czo_smollm_step_logits": (C.c_int, [vp, u32, vp]), "czo_smollm_reprime_logits": (C.c_int, [vp, vp, sz, vp]),
+        "czo_smollm_tensor_bf16": (vp, [vp, C.c_char_p, vp]), "czo_smollm_forward_rows": (C.c_int, [vp, vp, sz, sz, vp]),
+        "czo_smollm_encode_tokens": (sz, [vp, vp, sz, u32, u32, vp, vp, vp, vp]),
+        "czo_smollm_decode_tokens": (C.c_int, [vp, vp, sz, sz, u32, u32, u32, vp]),
+        "czo_free": (None, [vp]),
+        "czo_rwkv7_config_0b1": (None, [vp]), "czo_rwkv7_new_synthetic": (vp, [vp, u64, f32]), "czo_rwkv7_free": (None, [vp]),
+        "czo_rwkv7_vocab": (sz, [vp]), "czo_rwkv7_step_logits": (C.c_int, [vp, u32, vp]), "czo_rwkv7_reset": (None, [vp]),
+        "czo_rwkv7_tensor_bf16": (vp, [vp, C.c_char_p, vp]),
+        "czo_rwkv7_encode_tokens": (sz, [vp, vp, sz, vp, vp, vp, vp]),
+        "czo_rwkv7_decode_tokens": (C.c_int, [vp, vp, sz, sz, u32, vp]),
+        "czo_synth_bf16": (C.c_uint16, [u64, u32, u64, f32, f32]),
+        "czo_blake3_new": (vp, []), "czo_blake3_update": (None, [vp, vp, sz]), "czo_blake3_final16": (None, [vp, vp]),
+        "czo_blake3_free": (None, [vp]), "czo_blake3_bytes_bin16": (None, [vp, sz, vp]),
+        "czo_num_threads": (C.c_int, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data if a is not None else None
+
+
+# ---------------------------------------------------------------- pdf / cdf
+def softmax_pdf(logits):
+    logits = np.ascontiguousarray(logits, np.float32)
+    pdf = np.empty(logits.size, np.float64)
+    lib().czo_softmax_pdf(_p(logits), logits.size, _p(pdf))
+    return pdf
+
+
+def quantize_pdf_to_cdf(pdf):
+    pdf = np.ascontiguousarray(pdf, np.float64)
+    cdf = np.empty(pdf.size + 1, np.uint32)
+    lib().czo_quantize_pdf_to_cdf(_p(pdf), pdf.size, _p(cdf))
+    return cdf
+
+
+def combined_pdf_with_literals(logits):
+    logits = np.ascontiguousarray(logits, np.float32)
+    pdf = np.empty(logits.size + 256, np.float64)
+    lib().czo_combined_pdf_with_literals(_p(logits), logits.size, _p(pdf))
+    return pdf
+
+
+def logits_to_cdf(logits, backend="smollm"):
+    logits = np.ascontiguousarray(logits, np.float32)
+    if backend == "smollm":
+        cdf = np.empty(logits.size + 1, np.uint32)
+        lib().czo_logits_to_cdf_smollm(_p(logits), logits.size, _p(cdf))
+    else:
+        cdf = np.empty(logits.size + 257, np.uint32)
+        lib().czo_logits_to_cdf_rwkv(_p(logits), logits.size, _p(cdf))
+    return cdf
+
+
+# ---------------------------------------------------------------- arithmetic coder
+class ArithmeticEncoder:
+    def __init__(self):
+        self.e = Encoder()
+        lib().czo_enc_init(C.byref(self.e))
+
+    def encode_counts(self, c_lo, c_hi, total=AC_CDF_TOTAL):
+        lib().czo_enc_encode_counts(C.byref(self.e), int(c_lo), int(c_hi), int(total))
+
+    def finish(self):
+        out = C.c_void_p()
+        n = lib().czo_enc_finish(C.byref(self.e), C.byref(out))
+        data = C.string_at(out, n) if n else b""
+        self.zero_width = int(self.e.zero_width)
+        lib().czo_enc_free(C.byref(self.e))
+        return data
+
+
+class ArithmeticDecoder:
+    def __init__(self, payload: bytes):
+        self.buf = np.frombuffer(bytes(payload), np.uint8).copy() if len(payload) else np.zeros(1, np.uint8)
+        self.d = Decoder()
+        lib().czo_dec_init(C.byref(self.d), _p(self.buf), len(payload))
+
+    def decode_symbol_counts(self, cdf, total=AC_CDF_TOTAL):
+        cdf = np.ascontiguousarray(cdf, np.uint32)
+        return int(lib().czo_dec_decode_symbol_counts(C.byref(self.d), _p(cdf), cdf.size - 1, int(total)))
+
+
+def encode_pairs(c_lo, c_hi, total=AC_CDF_TOTAL):
+    """run A-4 over per-token (c_lo, c_hi) pairs -> payload bytes, zero_width count"""
+    e = ArithmeticEncoder()
+    for a, b in zip(np.asarray(c_lo).tolist(), np.asarray(c_hi).tolist()):
+        e.encode_counts(a, b, total)
+    data = e.finish()
+    return data, e.zero_width
+
+
+# ---------------------------------------------------------------- container
+def read_header(buf: bytes):
+    h = Header()
+    off = C.c_size_t()
+    a = np.frombuffer(buf, np.uint8)
+    n = lib().czo_read_header_v2(_p(a), len(buf), C.byref(h), C.byref(off))
+    if n == 0:
+        raise ValueError("bad header")
+    return h, bytes(buf[off.value:off.value + h.model_file_repr_len]), n
+
+
+def write_header(h: Header, repr_: bytes):
+    out = np.zeros(256 + len(repr_), np.uint8)
+    r = np.frombuffer(repr_, np.uint8) if repr_ else np.zeros(1, np.uint8)
+    h.model_file_repr_len = len(repr_)
+    n = lib().czo_write_header_v2(C.byref(h), _p(r), _p(out), out.size)
+    return out[:n].tobytes()
+
+
+def blake3_16(data: bytes) -> bytes:
+    a = np.frombuffer(data, np.uint8) if len(data) else np.zeros(1, np.uint8)
+    out = np.zeros(16, np.uint8)
+    lib().czo_blake3_bytes_bin16(_p(a), len(data), _p(out))
+    return out.tobytes()
+
+
+def blake3_16_parts(parts) -> bytes:
+    h = lib().czo_blake3_new()
+    for p in parts:
+        a = np.frombuffer(p, np.uint8) if len(p) else np.zeros(1, np.uint8)
+        lib().czo_blake3_update(h, _p(a), len(p))
+    out = np.zeros(16, np.uint8)
+    lib().czo_blake3_final16(h, _p(out))
+    lib().czo_blake3_free(h)
+    return out.tobytes()
+
+
+# ---------------------------------------------------------------- models
+def smollm2_135m_config():
+    c = LlamaConfig()
+    lib().czo_llama_config_smollm2_135m(C.byref(c))
+    return c
+
+
+def tiny_llama_config(vocab=512, d_model=128, n_layers=2, n_heads=2, n_kv_heads=1, d_ffn=256, max_pos=2048):
+    return LlamaConfig(vocab, d_model, n_layers, n_heads, n_kv_heads, d_ffn, max_pos, 100000.0, 1e-5)
+
+
+def rwkv7_0b1_config():
+    c = Rwkv7Config()
+    lib().czo_rwkv7_config_0b1(C.byref(c))
+    return c
+
+
+def tiny_rwkv7_config(vocab=512, hidden=128, n_layers=2, d_ffn=512):
+    return Rwkv7Config(vocab, hidden, n_layers, 64, d_ffn, 64, 64, 32, 128, 1e-5)
+
+
+class SmolLmSession:
+    """oracle mirror of src/models.rs:37-120 (synthetic weights)"""
+
+    def __init__(self, cfg, seed=0x5EED, embed_std=0.02):
+        self.cfg = cfg
+        self.h = lib().czo_smollm_new_synthetic(C.byref(cfg), seed, embed_std)
+        if not self.h:
+            raise ValueError("bad config")
+        self.V = cfg.vocab
+
+    def close(self):
+        if self.h:
+            lib().czo_smollm_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def vocab_size(self):
+        return self.V
+
+    def index_pos(self):
+        return int(lib().czo_smollm_index_pos(self.h))
+
+    def step_logits(self, tok):
+        out = np.empty(self.V, np.float32)
+        rc = lib().czo_smollm_step_logits(self.h, int(tok), _p(out))
+        assert rc == 0, rc
+        return out
+
+    def reprime_logits(self, hist):
+        hist = np.ascontiguousarray(hist, np.uint32)
+        out = np.empty(self.V, np.float32)
+        rc = lib().czo_smollm_reprime_logits(self.h, _p(hist), hist.size, _p(out))
+        assert rc == 0, rc
+        return out
+
+    def forward_rows(self, toks, first_row=0):
+        toks = np.ascontiguousarray(toks, np.uint32)
+        out = np.empty((toks.size - first_row, self.V), np.float32)
+        rc = lib().czo_smollm_forward_rows(self.h, _p(toks), toks.size, first_row, _p(out))
+        assert rc == 0, rc
+        return out
+
+    def tensor_bf16(self, name):
+        n = C.c_size_t()
+        p = lib().czo_smollm_tensor_bf16(self.h, name.encode(), C.byref(n))
+        if not p:
+            return None
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint16)), shape=(n.value,)).copy()
+
+    def tensor_names(self):
+        L = self.cfg.n_layers
+        names = ["model.embed_tokens.weight", "model.norm.weight"]
+        for i in range(L):
+            p = f"model.layers.{i}."
+            names += [p + s for s in ("input_layernorm.weight", "self_attn.q_proj.weight", "self_attn.k_proj.weight",
+                                      "self_attn.v_proj.weight", "self_attn.o_proj.weight", "post_attention_layernorm.weight",
+                                      "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight")]
+        return names
+
+    def encode_tokens(self, ids, context=512, reprime_interval=512):
+        ids = np.ascontiguousarray(ids, np.uint32)
+        n = ids.size
+        clo = np.zeros(max(n - 1, 1), np.uint32)
+        chi = np.zeros(max(n - 1, 1), np.uint32)
+        pay = C.c_void_p()
+        zw = C.c_uint64()
+        ln = lib().czo_smollm_encode_tokens(self.h, _p(ids), n, context, reprime_interval, _p(clo), _p(chi), C.byref(pay), C.byref(zw))
+        data = C.string_at(pay, ln) if ln else b""
+        lib().czo_free(pay)
+        return data, clo[:n - 1], chi[:n - 1], int(zw.value)
+
+    def decode_tokens(self, payload, token_count, context_window=512, reprime_interval=512, bos=0):
+        buf = np.frombuffer(bytes(payload), np.uint8).copy() if len(payload) else np.zeros(1, np.uint8)
+        out = np.zeros(token_count + 1, np.uint32)
+        rc = lib().czo_smollm_decode_tokens(self.h, _p(buf), len(payload), token_count, context_window, reprime_interval, bos, _p(out))
+        assert rc == 0
+        return out
+
+
+class Rwkv7Session:
+    """oracle mirror of src/models.rs:124-180 (synthetic weights)"""
+
+    def __init__(self, cfg, seed=0x5EED, embed_std=0.02):
+        self.cfg = cfg
+        self.h = lib().czo_rwkv7_new_synthetic(C.byref(cfg), seed, embed_std)
+        if not self.h:
+            raise ValueError("bad config")
+        self.V = cfg.vocab
+
+    def close(self):
+        if self.h:
+            lib().czo_rwkv7_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def vocab_size(self):
+        return self.V
+
+    def reset(self):
+        lib().czo_rwkv7_reset(self.h)
+
+    def step_logits(self, tok):
+        out = np.empty(self.V, np.float32)
+        rc = lib().czo_rwkv7_step_logits(self.h, int(tok), _p(out))
+        assert rc == 0, rc
+        return out
+
+    def tensor_bf16(self, name):
+        n = C.c_size_t()
+        p = lib().czo_rwkv7_tensor_bf16(self.h, name.encode(), C.byref(n))
+        if not p:
+            return None
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint16)), shape=(n.value,)).copy()
+
+    def encode_tokens(self, ids):
+        ids = np.ascontiguousarray(ids, np.uint32)
+        n = ids.size
+        clo = np.zeros(max(n - 1, 1), np.uint32)
+        chi = np.zeros(max(n - 1, 1), np.uint32)
+        pay = C.c_void_p()
+        zw = C.c_uint64()
+        ln = lib().czo_rwkv7_encode_tokens(self.h, _p(ids), n, _p(clo), _p(chi), C.byref(pay), C.byref(zw))
+        data = C.string_at(pay, ln) if ln else b""
+        lib().czo_free(pay)
+        return data, clo[:n - 1], chi[:n - 1], int(zw.value)
+
+    def decode_tokens(self, payload, token_count, bos=0):
+        buf = np.frombuffer(bytes(payload), np.uint8).copy() if len(payload) else np.zeros(1, np.uint8)
+        out = np.zeros(token_count + 1, np.uint32)
+        rc = lib().czo_rwkv7_decode_tokens(self.h, _p(buf), len(payload), token_count, bos, _p(out))
+        assert rc == 0
+        return out
