@@ -1,0 +1,277 @@
+"""candlezip_amd — host-side mirror (ctypes) of the MI355X-native candlezip hot path.
+
+The product is libcandlezip_hip.so (candlezip_amd/csrc, C ABI in include/candlezip.h).  This module only marshals
+arguments; it mirrors the reference's session trait (src/models.rs:28-33) and token loops so that tests read like the
+reference's call sites.  There is no CPU fallback: without the built library, or without a gfx950 device, every
+compute call raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcandlezip_hip.so")
+AC_CDF_TOTAL = 1 << 30
+
+BACKEND_SMOLLM, BACKEND_RWKV7 = 0, 1
+_STATUS = {0: "CZ_OK", 1: "CZ_ERR_ARG", 2: "CZ_ERR_IO", 3: "CZ_ERR_HIP", 4: "CZ_ERR_STATE", 5: "CZ_ERR_UNSUPPORTED", 6: "CZ_ERR_FORMAT"}
+
+
+class CandlezipError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"{_STATUS.get(status, status)}: {msg}")
+        self.status = status
+
+
+class LlamaConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in "vocab d_model n_layers n_heads n_kv_heads d_ffn max_pos".split()] + \
+               [("rope_theta", C.c_float), ("rms_eps", C.c_float)]
+
+
+class Rwkv7Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in "vocab hidden n_layers head_dim d_ffn a_rank decay_rank v_rank gate_rank".split()] + \
+               [("norm_eps", C.c_float)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("backend", C.c_int), ("weight_paths", C.POINTER(C.c_char_p)), ("n_weight_paths", C.c_size_t),
+                ("config_path", C.c_char_p), ("synthetic_seed", C.c_uint64), ("synthetic_embed_std", C.c_float),
+                ("llama", LlamaConfig), ("rwkv", Rwkv7Config), ("max_streams", C.c_uint32)]
+
+
+class Header(C.Structure):
+    _fields_ = [("bos_token_id", C.c_uint32), ("token_count", C.c_uint64), ("orig_len_bytes", C.c_uint64),
+                ("model_hash16", C.c_uint8 * 16), ("tokenizer_hash16", C.c_uint8 * 16), ("orig_hash16", C.c_uint8 * 16),
+                ("reserved_flags", C.c_uint32), ("context_window", C.c_uint32), ("vocab_size", C.c_uint32),
+                ("model_file_repr_len", C.c_uint32), ("reprime_interval", C.c_uint32)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+def smollm2_135m_config():
+    """HuggingFaceTB/SmolLM2-135M config.json (vocab confirmed by the reference's .canz headers)"""
+    return LlamaConfig(49152, 576, 30, 9, 3, 1536, 8192, 100000.0, 1e-5)
+
+
+def tiny_llama_config(vocab=512, d_model=128, n_layers=2, n_heads=2, n_kv_heads=1, d_ffn=256, max_pos=2048):
+    return LlamaConfig(vocab, d_model, n_layers, n_heads, n_kv_heads, d_ffn, max_pos, 100000.0, 1e-5)
+
+
+def rwkv7_0b1_config():
+    return Rwkv7Config(65536, 768, 12, 64, 3072, 64, 64, 32, 128, 1e-5)
+
+
+def tiny_rwkv7_config(vocab=512, hidden=128, n_layers=2, d_ffn=512):
+    return Rwkv7Config(vocab, hidden, n_layers, 64, d_ffn, 64, 64, 32, 128, 1e-5)
+
+
+EXPORTS = [  # every symbol include/candlezip.h declares
+    "cz_session_open", "cz_session_close", "cz_vocab_size", "cz_max_context_length", "cz_index_pos", "cz_step_logits",
+    "cz_reprime_logits", "cz_encode_tokens", "cz_encode_tokens_batch", "cz_decode_tokens", "cz_decode_tokens_batch",
+    "cz_ac_encode_pairs", "cz_free", "cz_write_header_v2", "cz_read_header_v2", "cz_flags_pack", "cz_skip_gate_section",
+    "cz_blake3_bytes_bin16", "cz_blake3_file_bin16", "cz_blake3_files_bin16", "cz_rwkv_tokenizer_open",
+    "cz_rwkv_tokenizer_close", "cz_rwkv_plan_symbols", "cz_rwkv_detok", "cz_last_error", "cz_profile_enable",
+    "cz_profile_read", "cz_synchronize",
+]
+
+_lib = None
+
+
+def lib():
+    """load libcandlezip_hip.so — raises loudly when it has not been built (no fallback of any kind)"""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). candlezip_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u32, u64 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64
+    sig = {
+        "cz_session_open": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(vp)]),
+        "cz_session_close": (None, [vp]), "cz_vocab_size": (sz, [vp]), "cz_max_context_length": (sz, [vp]), "cz_index_pos": (sz, [vp]),
+        "cz_step_logits": (C.c_int, [vp, u32, vp]), "cz_reprime_logits": (C.c_int, [vp, vp, sz, vp]),
+        "cz_encode_tokens": (C.c_int, [vp, vp, sz, u32, u32, vp, vp]),
+        "cz_encode_tokens_batch": (C.c_int, [vp, sz, vp, vp, u32, u32, vp, vp]),
+        "cz_decode_tokens": (C.c_int, [vp, vp, sz, sz, u32, u32, u32, vp]),
+        "cz_decode_tokens_batch": (C.c_int, [vp, sz, vp, vp, vp, u32, u32, u32, vp]),
+        "cz_ac_encode_pairs": (C.c_int, [vp, vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(u64)]),
+        "cz_free": (None, [vp]),
+        "cz_write_header_v2": (sz, [C.POINTER(Header), vp, vp, sz]),
+        "cz_read_header_v2": (C.c_int, [vp, sz, C.POINTER(Header), C.POINTER(sz), C.POINTER(sz)]),
+        "cz_flags_pack": (u32, [C.c_int, C.c_int, C.c_int, u32]),
+        "cz_skip_gate_section": (C.c_int, [vp, sz, C.POINTER(sz)]),
+        "cz_blake3_bytes_bin16": (None, [vp, sz, vp]), "cz_blake3_file_bin16": (C.c_int, [C.c_char_p, vp]),
+        "cz_blake3_files_bin16": (C.c_int, [C.POINTER(C.c_char_p), sz, vp]),
+        "cz_last_error": (C.c_char_p, []),
+        "cz_profile_enable": (C.c_int, [vp, C.c_int]), "cz_profile_read": (C.c_int, [vp, vp, sz, C.POINTER(sz)]),
+        "cz_synchronize": (C.c_int, [vp]),
+        "cz_debug_set": (C.c_int, [vp, C.c_char_p, C.c_long]),
+        "cz_debug_scalar": (C.c_int, [C.c_int, vp, vp, vp, C.c_int]), "cz_debug_f64": (C.c_int, [C.c_int, vp, vp, vp, C.c_int]),
+        "cz_debug_gemm": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "cz_debug_rmsnorm": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_float]),
+        "cz_debug_cdf_pairs": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
+        "cz_debug_decode_symbols": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, sz, vp]),
+        "cz_debug_attention": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        if hasattr(L, name):
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise CandlezipError(rc, (lib().cz_last_error() or b"").decode("utf-8", "replace"))
+
+
+def _p(a):
+    return a.ctypes.data if a is not None else None
+
+
+def _ptr_array(arrs):
+    return (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+
+
+class Session:
+    """mirror of `trait LanguageModelSession` (src/models.rs:28-33) + the fused encode/decode loops"""
+
+    def __init__(self, backend="smollm", config=None, weight_paths=(), config_path=None, seed=0x5EED, embed_std=0.02,
+                 device=0, max_streams=64):
+        L = lib()
+        d = ModelDesc()
+        d.backend = {"smollm": BACKEND_SMOLLM, "rwkv7": BACKEND_RWKV7}[backend.lower()]     # --backend (src/main.rs:1799)
+        self._paths = [p.encode() for p in weight_paths]
+        if self._paths:
+            arr = (C.c_char_p * len(self._paths))(*self._paths)
+            d.weight_paths = C.cast(arr, C.POINTER(C.c_char_p))
+            self._arr = arr
+        d.n_weight_paths = len(self._paths)
+        d.config_path = config_path.encode() if config_path else None
+        d.synthetic_seed, d.synthetic_embed_std, d.max_streams = seed, embed_std, max_streams
+        if d.backend == BACKEND_SMOLLM:
+            d.llama = config if config is not None else smollm2_135m_config()
+        else:
+            d.rwkv = config if config is not None else rwkv7_0b1_config()
+        self.backend = backend.lower()
+        self.h = C.c_void_p()
+        _check(L.cz_session_open(C.byref(d), device, C.byref(self.h)))
+        self.V = int(L.cz_vocab_size(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cz_session_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- trait methods
+    def vocab_size(self):
+        return self.V
+
+    def max_context_length(self):
+        return int(lib().cz_max_context_length(self.h))
+
+    def index_pos(self):
+        return int(lib().cz_index_pos(self.h))
+
+    def step_logits_tensor(self, token_id):
+        out = np.empty(self.V, np.float32)
+        _check(lib().cz_step_logits(self.h, int(token_id), _p(out)))
+        return out
+
+    def reprime_with_history_and_get_last_logits_tensor(self, history):
+        history = np.ascontiguousarray(history, np.uint32)
+        out = np.empty(self.V, np.float32)
+        _check(lib().cz_reprime_logits(self.h, _p(history), history.size, _p(out)))
+        return out
+
+    # ---- fused loops
+    def encode_tokens_batch(self, ids_list, context=512, reprime_interval=512):
+        ids_list = [np.ascontiguousarray(a, np.uint32) for a in ids_list]
+        n = np.array([a.size for a in ids_list], np.uint64)
+        los = [np.zeros(max(a.size - 1, 1), np.uint32) for a in ids_list]
+        his = [np.zeros(max(a.size - 1, 1), np.uint32) for a in ids_list]
+        _check(lib().cz_encode_tokens_batch(self.h, len(ids_list), _ptr_array(ids_list), _p(n), context, reprime_interval,
+                                            _ptr_array(los), _ptr_array(his)))
+        return [(lo[:a.size - 1], hi[:a.size - 1]) for a, lo, hi in zip(ids_list, los, his)]
+
+    def encode_tokens(self, ids, context=512, reprime_interval=512):
+        return self.encode_tokens_batch([ids], context, reprime_interval)[0]
+
+    def decode_tokens_batch(self, payloads, token_counts, context_window=512, reprime_interval=512, bos=0):
+        bufs = [np.frombuffer(bytes(p), np.uint8).copy() if len(p) else np.zeros(1, np.uint8) for p in payloads]
+        lens = np.array([len(p) for p in payloads], np.uint64)
+        tcs = np.array(token_counts, np.uint64)
+        outs = [np.zeros(int(t) + 1, np.uint32) for t in token_counts]
+        _check(lib().cz_decode_tokens_batch(self.h, len(payloads), _ptr_array(bufs), _p(lens), _p(tcs), context_window,
+                                            reprime_interval, bos, _ptr_array(outs)))
+        return outs
+
+    def decode_tokens(self, payload, token_count, context_window=512, reprime_interval=512, bos=0):
+        return self.decode_tokens_batch([payload], [token_count], context_window, reprime_interval, bos)[0]
+
+    # ---- measurement
+    def profile_enable(self, on=True):
+        _check(lib().cz_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        arr = (KernelStat * 32)()
+        n = C.c_size_t()
+        _check(lib().cz_profile_read(self.h, arr, 32, C.byref(n)))
+        return {arr[i].name.decode(): dict(launches=int(arr[i].launches), total_ms=arr[i].total_ms, flops=arr[i].flops, bytes=arr[i].bytes)
+                for i in range(n.value)}
+
+    def synchronize(self):
+        _check(lib().cz_synchronize(self.h))
+
+    def debug_set(self, key, value):
+        _check(lib().cz_debug_set(self.h, key.encode(), int(value)))
+
+    def param_count(self):
+        c = None
+        return c
+
+
+# ---- host-side coder / container (reference: ArithmeticEncoder, write/read_header_v2, blake3 helpers)
+def ac_encode_pairs(c_lo, c_hi):
+    c_lo = np.ascontiguousarray(c_lo, np.uint32)
+    c_hi = np.ascontiguousarray(c_hi, np.uint32)
+    pay, ln, zw = C.c_void_p(), C.c_size_t(), C.c_uint64()
+    _check(lib().cz_ac_encode_pairs(_p(c_lo), _p(c_hi), c_lo.size, C.byref(pay), C.byref(ln), C.byref(zw)))
+    data = C.string_at(pay, ln.value) if ln.value else b""
+    lib().cz_free(pay)
+    return data, int(zw.value)
+
+
+def write_header(h: Header, model_file_repr: bytes) -> bytes:
+    h.model_file_repr_len = len(model_file_repr)
+    out = np.zeros(128 + len(model_file_repr), np.uint8)
+    r = np.frombuffer(model_file_repr, np.uint8) if model_file_repr else np.zeros(1, np.uint8)
+    n = lib().cz_write_header_v2(C.byref(h), _p(r), _p(out), out.size)
+    if n == 0:
+        raise CandlezipError(1, "header buffer too small")
+    return out[:n].tobytes()
+
+
+def read_header(buf: bytes):
+    a = np.frombuffer(buf, np.uint8)
+    h, off, used = Header(), C.c_size_t(), C.c_size_t()
+    _check(lib().cz_read_header_v2(_p(a), len(buf), C.byref(h), C.byref(off), C.byref(used)))
+    return h, bytes(buf[off.value:off.value + h.model_file_repr_len]), used.value
+
+
+def blake3_16(data: bytes) -> bytes:
+    a = np.frombuffer(data, np.uint8) if len(data) else np.zeros(1, np.uint8)
+    out = np.zeros(16, np.uint8)
+    lib().cz_blake3_bytes_bin16(_p(a), len(data), _p(out))
+    return out.tobytes()

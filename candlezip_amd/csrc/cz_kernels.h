@@ -1,0 +1,50 @@
+// cz_kernels.h — launchers of the HIP kernels (internal to libcandlezip_hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "cz_numerics.h"
+
+// one attention "sequence": rows [row0, row0+nrows) of the activation batch sit at positions pos0.. and attend to
+// keys/values k[j*kv_stride + kvh*64 + d], j in [0, pos0 + local_row]
+struct cz_seq_desc {
+    int row0, nrows, pos0, kv_stride;
+    const float* k;
+    const float* v;
+};
+
+// rows [row0, row0+nrows) are RoPE'd at positions pos0..; K (RoPE'd) and V are written to k_dst/v_dst rows pos0..
+struct cz_rope_desc {
+    int row0, nrows, pos0, dst_stride;
+    float* k_dst;
+    float* v_dst;
+};
+
+hipError_t cz_launch_gemm(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R, int ldr,
+                          int M, int N, int K, int force_big);
+hipError_t cz_launch_embed(hipStream_t st, const uint32_t* tok, const uint16_t* E, float* X, int M, int d);
+hipError_t cz_launch_rmsnorm(hipStream_t st, const float* X, int ldx, const uint16_t* w, float* Y, int ldy, int M, int d, float eps,
+                             const int* row_index);
+hipError_t cz_launch_rope(hipStream_t st, float* QKV, int ld, const cz_rope_desc* descs, int nseq, int max_rows, int n_heads,
+                          int n_kv, const float* cs, const float* sn, size_t kv_off, const int* pos_dev);
+hipError_t cz_launch_swiglu(hipStream_t st, const float* GU, float* H, int M, int f);
+hipError_t cz_launch_attention(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nseq,
+                               int max_rows, int max_nk, int n_heads, int n_kv, size_t kv_off, const int* pos_dev);
+size_t cz_attention_smem_bytes(int max_nk);
+hipError_t cz_attention_prepare(int max_nk);
+
+// logits -> coder interval of `sym` (encode) ; mode 0 = smollm (softmax_pdf), 1 = rwkv7 (floor + 256 literals)
+hipError_t cz_launch_cdf_pairs(hipStream_t st, const float* logits, int ld, const uint32_t* sym, uint32_t* c_lo, uint32_t* c_hi,
+                               int rows, int vocab, int mode);
+// device-resident arithmetic decoder state, one per stream (src/main.rs:406-417)
+struct cz_dec_state {
+    unsigned long long low, high, code;
+    unsigned long long byte_pos;
+    unsigned int bit_pos, active;
+    const uint8_t* in;
+    unsigned long long in_len;
+    uint32_t* out_ids;            // out_ids[0] = bos, out_ids[i+1] = i-th decoded symbol
+    unsigned long long token_count;
+};
+hipError_t cz_launch_dec_init(hipStream_t st, cz_dec_state* st_arr, int nstreams);
+hipError_t cz_launch_decode_symbol(hipStream_t st, const float* logits, int ld, cz_dec_state* st_arr, uint32_t* sym_out, int nstreams,
+                                   int vocab, int mode, unsigned long long i);

@@ -1,0 +1,69 @@
+// cz_session.h — the session object behind the opaque cz_session handle (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "../../include/candlezip.h"
+#include "cz_kernels.h"
+
+#define CZ_MAX_CTX 2048      // longest attention window the kernels keep in LDS (reference sawtooth peaks at 1535)
+
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    cz_status ensure(size_t bytes);
+    void release();
+};
+
+enum ProfKind { PK_GEMM = 0, PK_GEMM_SKINNY, PK_ATTN, PK_RMSNORM, PK_ROPE, PK_SWIGLU, PK_EMBED, PK_CDF, PK_DECODE, PK_RWKV, PK_COUNT };
+struct ProfAcc { uint64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
+struct ProfEvt { hipEvent_t e0, e1; int kind; double flops, bytes; };
+
+struct LlamaModel {
+    cz_llama_config cfg{};
+    uint16_t* blob = nullptr;          // one allocation: E | per-layer tensors | lnf   (bf16)
+    uint16_t* E = nullptr;             // [vocab][d]  (tied lm_head)
+    struct Layer { uint16_t *ln1, *wqkv, *wo, *ln2, *wgu, *wd; };
+    std::vector<Layer> L;
+    uint16_t* lnf = nullptr;
+    float *rope_cos = nullptr, *rope_sin = nullptr;   // [max_pos][32]
+    size_t param_count = 0;
+};
+
+struct Rwkv7Model;   // rwkv7.hip
+
+struct cz_session {
+    cz_backend backend = CZ_BACKEND_SMOLLM;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint64_t seed = 0;
+    LlamaModel llama;
+    Rwkv7Model* rwkv = nullptr;
+    // packed-row work buffers
+    DevBuf tok, x, xn, qkv, gu, h, seqd, roped, rowidx, sym, clo, chi, xl, logits, payload, outids, decst;
+    size_t max_batch_rows = 98304, logit_batch_rows = 8192;
+    int force_big_gemm = 0;
+    // lock-step streams
+    int max_streams = 64;
+    size_t ctx_cap = 0, kv_layer_stride = 0, kv_stream_stride = 0;
+    float* kvcache = nullptr;          // [stream][layer][K|V][ctx_cap][n_kv*64]
+    int* pos_dev = nullptr;
+    cz_seq_desc* step_seqd = nullptr; cz_rope_desc* step_roped = nullptr; int* step_rows = nullptr;
+    float* step_logits = nullptr; uint32_t* step_sym = nullptr;
+    size_t index_pos = 0;              // SmolLmSession::index_pos (src/models.rs:65)
+    // profiling
+    bool prof_on = false;
+    ProfAcc acc[PK_COUNT];
+    std::vector<ProfEvt> evts; std::vector<hipEvent_t> evt_free; ProfEvt evt_open{};
+    void prof_begin(int kind);
+    void prof_end(double flops, double bytes);
+    void prof_drain();
+};
+
+// rwkv7.hip
+cz_status cz_rwkv7_build(cz_session* s, const cz_model_desc* desc);
+void cz_rwkv7_destroy(cz_session* s);
+size_t cz_rwkv7_vocab(const cz_session* s);
+cz_status cz_rwkv7_step_host(cz_session* s, uint32_t token, float* out_logits);
+cz_status cz_rwkv7_reprime_host(cz_session* s, const uint32_t* hist, size_t n, float* out_logits);
+cz_status cz_rwkv7_encode(cz_session* s, size_t n_streams, const uint32_t* const* ids, const size_t* n, uint32_t* const* lo, uint32_t* const* hi);
+cz_status cz_rwkv7_decode_group(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs, uint32_t bos,
+                                uint32_t* const* out_ids);

@@ -1,0 +1,246 @@
+// kernels_gemm.hip — C[M,N] = A[M,K] (f32) x W[N,K]^T (bf16, widened exactly) in the canonical reduction order.
+//
+// Replaces the Linear layers candle runs through the `gemm` crate on the reference CPU path (call sites
+// src/models.rs:94, :110; candle_rwkv7/src/models/rwkv7.rs:206-236, 324, 426-428, 518).
+//
+// Canonical order (DESIGN.md "Numerics"): K is cut into chunks of 64; inside a chunk the partial sum is the
+// fmaf chain k ascending from +0 — which is bit for bit what a chain of v_mfma_f32_32x32x2_f32 / 16x16x4_f32
+// computes — and chunk partials are added left to right in f32 on the VALU.  One LDS K-tile == one chunk.
+//
+// gemm_bf16w_kernel   : big-M (prefill / segment-parallel encode).  Bound: f32 MFMA (157.3 TFLOP/s peak).
+//                       Algorithmic flops per launch = 2*M*N*K.
+// gemm_skinny_kernel  : M <= 64 (lock-step decode).  K chunks are spread over the waves of a block, the chunk
+//                       partials meet in LDS and are summed in chunk order.  Latency/HBM-bound.
+#include "cz_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LDK 68   // LDS row stride in floats (64 + 4): ds_read_b128 by 16 consecutive rows is conflict-free
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    // blocks b and b+8 share an XCD (observed round-robin dispatch; speed only, never correctness):
+    // give each XCD a contiguous range of tiles so that tiles sharing an A row-panel hit one L2.
+    int q = nblocks >> 3, r = nblocks & 7, x = bid & 7;
+    int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_bf16w_kernel(const float* __restrict__ A, int lda,
+                                                         const uint16_t* __restrict__ W, float* __restrict__ C, int ldc,
+                                                         const float* __restrict__ R, int ldr, int M, int N, int K,
+                                                         int nbx, int nblocks) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int PA = BM / 32, PB = BN / 32;     // staging passes (256 threads x 8 k-values per pass)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + BM * LDK;
+
+    const int sid = xcd_remap(blockIdx.x, nblocks);
+    const int bm = sid / nbx, bn = sid % nbx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    f32x4 ra[PA][2];
+    uint4 rb[PB];
+    const int srow = tid >> 3, sg = tid & 7;      // staging: row within a 32-row pass, 8-wide k group
+
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            int row = bm * BM + p * 32 + srow;
+            if (row < M) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(A + (size_t)row * lda + kt * 64 + sg * 8);
+                ra[p][0] = src[0]; ra[p][1] = src[1];
+            } else {
+                ra[p][0] = f32x4{0, 0, 0, 0}; ra[p][1] = f32x4{0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            int n = bn * BN + p * 32 + srow;
+            rb[p] = *reinterpret_cast<const uint4*>(W + (size_t)n * K + kt * 64 + sg * 8);
+        }
+    };
+    // LDS image: within every group of 8 k-values the even k come first, then the odd k, so that the b128 read of
+    // lane-half h (4 floats at 8g + 4h) yields k = 8g + 2j + h, j = 0..3: exactly the A/B operand of MFMA step
+    // t = 4g + j (lane l holds k = 2t + (l >> 5)); the fmaf chain therefore runs over k ascending.
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            float* dst = As + (p * 32 + srow) * LDK + sg * 8;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{ra[p][0][0], ra[p][0][2], ra[p][1][0], ra[p][1][2]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{ra[p][0][1], ra[p][0][3], ra[p][1][1], ra[p][1][3]};
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            float* dst = Bs + (p * 32 + srow) * LDK + sg * 8;
+            uint4 w = rb[p];
+            *reinterpret_cast<f32x4*>(dst) = f32x4{cz_bits_f32(w.x << 16), cz_bits_f32(w.y << 16), cz_bits_f32(w.z << 16), cz_bits_f32(w.w << 16)};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{cz_bits_f32(w.x & 0xffff0000u), cz_bits_f32(w.y & 0xffff0000u),
+                                                      cz_bits_f32(w.z & 0xffff0000u), cz_bits_f32(w.w & 0xffff0000u)};
+        }
+    };
+
+    f32x16 tot[TM][TN];
+    const int nk = K / 64;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile(kt + 1);            // global loads in flight under the MFMA chain
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(As + ((wm * TM + i) * 32 + lr) * LDK + g * 8 + lh * 4);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(Bs + ((wn * TN + j) * 32 + lr) * LDK + g * 8 + lh * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (kt == 0) tot[i][j] = acc[i][j];
+                else
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tot[i][j][r] = tot[i][j][r] + acc[i][j][r];
+            }
+        __syncthreads();                                // every wave is done reading this K tile
+        if (kt + 1 < nk) { store_tile(); __syncthreads(); }
+    }
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = bn * BN + (wn * TN + j) * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bm * BM + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < M) {
+                    float v = tot[i][j][r];
+                    if (R) v = v + R[(size_t)row * ldr + col];
+                    C[(size_t)row * ldc + col] = v;
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Skinny GEMM, M <= 64 rows.  Block = NCOL(16|32)-column slab of W x all rows; 8 waves; wave w owns K chunks
+// w, w+8, ...  Per chunk: A fragment A[i = l&15][k = 4t + (l>>4)] straight from global (tiny, L2-resident),
+// B fragment from the bf16 weights W[n = n0 + (l&15)][k], v_mfma_f32_16x16x4_f32 chain t = 0..15 (k ascending).
+// Chunk partials go to LDS and are summed in chunk order round by round (8 chunks per round).
+template <int MT>   // number of 16-row tiles (1..4)
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(const float* __restrict__ A, int lda,
+                                                          const uint16_t* __restrict__ W, float* __restrict__ C, int ldc,
+                                                          const float* __restrict__ R, int ldr, int M, int N, int K) {
+    __shared__ float part[8][MT * 16][16 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int li = lane & 15, lg = lane >> 4;
+    const int nch = K / 64;
+    // ordered accumulation: thread `tid` owns output elements (row = tid / 16 + 32 * e, col = tid % 16), e = 0, 1
+    const int orow = tid >> 4, ocol = tid & 15;
+    float total[2] = {0.0f, 0.0f};
+    for (int c0 = 0; c0 < nch; c0 += 8) {
+        const int c = c0 + wave;
+        if (c < nch) {
+            f32x4 acc[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = f32x4{0, 0, 0, 0};
+            const uint16_t* wrow = W + (size_t)(n0 + li) * K + c * 64;
+#pragma unroll 4
+            for (int t = 0; t < 16; ++t) {
+                float b = cz_bf16_to_f32(wrow[4 * t + lg]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    int row = m * 16 + li;
+                    float a = row < M ? A[(size_t)row * lda + c * 64 + 4 * t + lg] : 0.0f;
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[m], 0, 0, 0);
+                }
+            }
+            // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[wave][m * 16 + 4 * lg + r][li] = acc[m][r];
+        }
+        __syncthreads();
+        const int lim = nch - c0 < 8 ? nch - c0 : 8;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int row = orow + 32 * e;
+            if (row < MT * 16)
+                for (int w = 0; w < lim; ++w) {
+                    float p = part[w][row][ocol];
+                    total[e] = (c0 + w == 0) ? p : total[e] + p;
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int row = orow + 32 * e;
+        if (row < MT * 16 && row < M) {
+            float v = total[e];
+            if (R) v = v + R[(size_t)row * ldr + n0 + ocol];
+            C[(size_t)row * ldc + n0 + ocol] = v;
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_big(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R,
+                             int ldr, int M, int N, int K) {
+    static bool attr_set = false;
+    const size_t smem = (size_t)(BM + BN) * LDK * sizeof(float);
+    auto kern = gemm_bf16w_kernel<BM, BN, WM, WN>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nbx = N / BN, nby = (M + BM - 1) / BM, nblocks = nbx * nby;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, st, A, lda, W, C, ldc, R, ldr, M, N, K, nbx, nblocks);
+    return hipGetLastError();
+}
+
+hipError_t cz_launch_gemm(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R, int ldr,
+                          int M, int N, int K, int force_big) {
+    if (M <= 0) return hipSuccess;
+    if (K % 64 != 0 || N % 16 != 0) return hipErrorInvalidValue;
+    if (M <= 64 && !force_big) {
+        const int mt = (M + 15) / 16;
+        dim3 grid(N / 16), block(512);
+        switch (mt) {
+            case 1: hipLaunchKernelGGL(gemm_skinny_kernel<1>, grid, block, 0, st, A, lda, W, C, ldc, R, ldr, M, N, K); break;
+            case 2: hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, block, 0, st, A, lda, W, C, ldc, R, ldr, M, N, K); break;
+            case 3: hipLaunchKernelGGL(gemm_skinny_kernel<3>, grid, block, 0, st, A, lda, W, C, ldc, R, ldr, M, N, K); break;
+            default: hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, block, 0, st, A, lda, W, C, ldc, R, ldr, M, N, K); break;
+        }
+        return hipGetLastError();
+    }
+    if (N % 64 != 0) return hipErrorInvalidValue;
+    if (N % 128 == 0) return launch_big<128, 128, 2, 2>(st, A, lda, W, C, ldc, R, ldr, M, N, K);
+    return launch_big<128, 64, 2, 2>(st, A, lda, W, C, ldc, R, ldr, M, N, K);
+}

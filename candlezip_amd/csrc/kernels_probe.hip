@@ -1,0 +1,173 @@
+// kernels_probe.hip — per-kernel entry points for the GPU parity tests (host pointers in, host pointers out).
+// Not part of the drop-in boundary; they exist so that tests/ can compare every kernel with the oracle in isolation
+// (a whole-model tolerance would hide an O(1)-wrong sub-stage).
+#include <string.h>
+#include <vector>
+#include "cz_host.h"
+#include "cz_kernels.h"
+
+#define PCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cz_set_error("HIP error %s at %s:%d", hipGetErrorString(_e), __FILE__, __LINE__); goto fail; } } while (0)
+
+struct DevMem {
+    std::vector<void*> ptrs;
+    void* alloc(size_t n) { void* p = nullptr; if (hipMalloc(&p, n ? n : 4) != hipSuccess) return nullptr; ptrs.push_back(p); return p; }
+    ~DevMem() { for (auto p : ptrs) { hipError_t e = hipFree(p); (void)e; } }
+};
+
+__global__ void scalar_fn_kernel(int fn, const float* x, const float* y, float* out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = x[i], b = y ? y[i] : 0.0f, r;
+    switch (fn) {
+        case 0: r = cz_expf(a); break;
+        case 1: r = cz_logf(a); break;
+        case 2: r = cz_tanhf(a); break;
+        case 3: r = a / b; break;
+        case 4: r = sqrtf(a); break;
+        case 5: r = cz_siluf(a); break;
+        case 6: r = cz_sigmoidf(a); break;
+        case 7: r = a * b; break;
+        case 8: r = cz_fma(a, b, a); break;
+        default: r = 0.0f;
+    }
+    out[i] = r;
+}
+__global__ void f64_fn_kernel(int fn, const double* x, const double* y, double* out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a = x[i], b = y[i], r;
+    switch (fn) {
+        case 0: r = a / b; break;
+        case 1: r = a + b; break;
+        case 2: r = floor(a * 1073741824.0); break;
+        case 3: r = a * b; break;
+        default: r = 0.0;
+    }
+    out[i] = r;
+}
+
+extern "C" cz_status cz_debug_scalar(int fn, const float* x, const float* y, float* out, int n) {
+    DevMem m;
+    float *dx = (float*)m.alloc(n * 4), *dy = (float*)m.alloc(n * 4), *dout = (float*)m.alloc(n * 4);
+    if (!dx || !dy || !dout) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
+    PCHK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+    if (y) PCHK(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(scalar_fn_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, fn, dx, y ? dy : nullptr, dout, n);
+    PCHK(hipGetLastError());
+    PCHK(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    return CZ_OK;
+fail:
+    return CZ_ERR_HIP;
+}
+extern "C" cz_status cz_debug_f64(int fn, const double* x, const double* y, double* out, int n) {
+    DevMem m;
+    double *dx = (double*)m.alloc(n * 8), *dy = (double*)m.alloc(n * 8), *dout = (double*)m.alloc(n * 8);
+    if (!dx || !dy || !dout) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
+    PCHK(hipMemcpy(dx, x, n * 8, hipMemcpyHostToDevice));
+    PCHK(hipMemcpy(dy, y, n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(f64_fn_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, fn, dx, dy, dout, n);
+    PCHK(hipGetLastError());
+    PCHK(hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost));
+    return CZ_OK;
+fail:
+    return CZ_ERR_HIP;
+}
+
+// C = A . W^T (+ R), A f32 [M][K], W bf16 [N][K]
+extern "C" cz_status cz_debug_gemm(const float* A, const uint16_t* W, const float* R, float* C, int M, int N, int K, int force_big) {
+    DevMem m;
+    float *dA = (float*)m.alloc((size_t)M * K * 4), *dC = (float*)m.alloc((size_t)M * N * 4), *dR = R ? (float*)m.alloc((size_t)M * N * 4) : nullptr;
+    uint16_t* dW = (uint16_t*)m.alloc((size_t)N * K * 2);
+    if (!dA || !dC || !dW || (R && !dR)) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
+    PCHK(hipMemcpy(dA, A, (size_t)M * K * 4, hipMemcpyHostToDevice));
+    PCHK(hipMemcpy(dW, W, (size_t)N * K * 2, hipMemcpyHostToDevice));
+    if (R) PCHK(hipMemcpy(dR, R, (size_t)M * N * 4, hipMemcpyHostToDevice));
+    PCHK(hipMemset(dC, 0xFF, (size_t)M * N * 4));
+    PCHK(cz_launch_gemm(0, dA, K, dW, dC, N, dR, N, M, N, K, force_big));
+    PCHK(hipDeviceSynchronize());
+    PCHK(hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    return CZ_OK;
+fail:
+    return CZ_ERR_HIP;
+}
+
+extern "C" cz_status cz_debug_rmsnorm(const float* X, const uint16_t* w, float* Y, int M, int d, float eps) {
+    DevMem m;
+    float *dX = (float*)m.alloc((size_t)M * d * 4), *dY = (float*)m.alloc((size_t)M * d * 4);
+    uint16_t* dw = (uint16_t*)m.alloc((size_t)d * 2);
+    if (!dX || !dY || !dw) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
+    PCHK(hipMemcpy(dX, X, (size_t)M * d * 4, hipMemcpyHostToDevice));
+    PCHK(hipMemcpy(dw, w, (size_t)d * 2, hipMemcpyHostToDevice));
+    PCHK(cz_launch_rmsnorm(0, dX, d, dw, dY, d, M, d, eps, nullptr));
+    PCHK(hipDeviceSynchronize());
+    PCHK(hipMemcpy(Y, dY, (size_t)M * d * 4, hipMemcpyDeviceToHost));
+    return CZ_OK;
+fail:
+    return CZ_ERR_HIP;
+}
+
+// logits [rows][V] -> (c_lo, c_hi) of sym[rows]
+extern "C" cz_status cz_debug_cdf_pairs(const float* logits, const uint32_t* sym, uint32_t* c_lo, uint32_t* c_hi, int rows, int V, int mode) {
+    DevMem m;
+    float* dl = (float*)m.alloc((size_t)rows * V * 4);
+    uint32_t *ds = (uint32_t*)m.alloc(rows * 4), *dlo = (uint32_t*)m.alloc(rows * 4), *dhi = (uint32_t*)m.alloc(rows * 4);
+    if (!dl || !ds || !dlo || !dhi) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
+    PCHK(hipMemcpy(dl, logits, (size_t)rows * V * 4, hipMemcpyHostToDevice));
+    PCHK(hipMemcpy(ds, sym, rows * 4, hipMemcpyHostToDevice));
+    PCHK(cz_launch_cdf_pairs(0, dl, V, ds, dlo, dhi, rows, V, mode));
+    PCHK(hipDeviceSynchronize());
+    PCHK(hipMemcpy(c_lo, dlo, rows * 4, hipMemcpyDeviceToHost));
+    PCHK(hipMemcpy(c_hi, dhi, rows * 4, hipMemcpyDeviceToHost));
+    return CZ_OK;
+fail:
+    return CZ_ERR_HIP;
+}
+
+// decode `steps` symbols of ONE stream from `payload`, using logits[step][V] (teacher-provided), on the device
+extern "C" cz_status cz_debug_decode_symbols(const float* logits, int steps, int V, int mode, const uint8_t* payload, size_t len,
+                                             uint32_t* out_syms) {
+    DevMem m;
+    float* dl = (float*)m.alloc((size_t)steps * V * 4);
+    uint8_t* dp = (uint8_t*)m.alloc(len + 16);
+    uint32_t* dout = (uint32_t*)m.alloc((size_t)(steps + 1) * 4);
+    uint32_t* dsym = (uint32_t*)m.alloc(64);
+    cz_dec_state* dst = (cz_dec_state*)m.alloc(sizeof(cz_dec_state));
+    cz_dec_state hs;
+    if (!dl || !dp || !dout || !dsym || !dst) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
+    PCHK(hipMemcpy(dl, logits, (size_t)steps * V * 4, hipMemcpyHostToDevice));
+    if (len) PCHK(hipMemcpy(dp, payload, len, hipMemcpyHostToDevice));
+    memset(&hs, 0, sizeof hs);
+    hs.in = dp; hs.in_len = len; hs.out_ids = dout; hs.token_count = (unsigned long long)steps; hs.active = 1;
+    PCHK(hipMemcpy(dst, &hs, sizeof hs, hipMemcpyHostToDevice));
+    PCHK(cz_launch_dec_init(0, dst, 1));
+    for (int i = 0; i < steps; ++i) PCHK(cz_launch_decode_symbol(0, dl + (size_t)i * V, V, dst, dsym, 1, V, mode, (unsigned long long)i));
+    PCHK(hipDeviceSynchronize());
+    PCHK(hipMemcpy(out_syms, dout + 1, (size_t)steps * 4, hipMemcpyDeviceToHost));
+    return CZ_OK;
+fail:
+    return CZ_ERR_HIP;
+}
+
+// rows at positions pos0.. attend to K/V rows [0, pos0+m]; Q/O [M][nh*64], K/V [pos0+M][nkv*64]
+extern "C" cz_status cz_debug_attention(const float* Q, const float* K, const float* V, float* O, int M, int pos0, int nh, int nkv) {
+    DevMem m;
+    const int nk = pos0 + M;
+    float *dQ = (float*)m.alloc((size_t)M * nh * 64 * 4), *dO = (float*)m.alloc((size_t)M * nh * 64 * 4);
+    float *dK = (float*)m.alloc((size_t)nk * nkv * 64 * 4), *dV = (float*)m.alloc((size_t)nk * nkv * 64 * 4);
+    cz_seq_desc* dd = (cz_seq_desc*)m.alloc(sizeof(cz_seq_desc));
+    cz_seq_desc hd;
+    if (!dQ || !dO || !dK || !dV || !dd) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
+    PCHK(hipMemcpy(dQ, Q, (size_t)M * nh * 64 * 4, hipMemcpyHostToDevice));
+    PCHK(hipMemcpy(dK, K, (size_t)nk * nkv * 64 * 4, hipMemcpyHostToDevice));
+    PCHK(hipMemcpy(dV, V, (size_t)nk * nkv * 64 * 4, hipMemcpyHostToDevice));
+    PCHK(hipMemset(dO, 0xFF, (size_t)M * nh * 64 * 4));
+    hd.row0 = 0; hd.nrows = M; hd.pos0 = pos0; hd.kv_stride = nkv * 64; hd.k = dK; hd.v = dV;
+    PCHK(hipMemcpy(dd, &hd, sizeof hd, hipMemcpyHostToDevice));
+    PCHK(cz_attention_prepare(2048));
+    PCHK(cz_launch_attention(0, dQ, nh * 64, dO, nh * 64, dd, 1, M, nk, nh, nkv, 0, nullptr));
+    PCHK(hipDeviceSynchronize());
+    PCHK(hipMemcpy(O, dO, (size_t)M * nh * 64 * 4, hipMemcpyDeviceToHost));
+    return CZ_OK;
+fail:
+    return CZ_ERR_HIP;
+}

@@ -1,0 +1,627 @@
+// session.hip — model sessions, segment-parallel encode, lock-step decode and the C ABI (include/candlezip.h).
+//
+// Mirrors the reference's session object and token loops:
+//   SmolLmSession (src/models.rs:37-120)            -> cz_session + cz_step_logits / cz_reprime_logits
+//   encode_file loop  (src/main.rs:1913-1916, 1935, 1979, 2275-2300, 2344-2345)   -> cz_encode_tokens[_batch]
+//   decode_file loop  (src/main.rs:2485, 2506, 2528-2541, 2621-2628)              -> cz_decode_tokens[_batch]
+// Design: encode is teacher-forced, so every re-prime segment is an independent causal forward; all
+// segments of all streams are packed row-wise into shared f32-MFMA GEMMs.  Decode steps B independent streams in
+// lock-step; the arithmetic-decoder state, the decoded ids and the position counter live in HBM, the host only
+// enqueues kernels (no per-token synchronisation).
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+#include "cz_host.h"
+#include "cz_kernels.h"
+#include "cz_session.h"
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            cz_set_error("HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
+            return CZ_ERR_HIP;                                                                         \
+        }                                                                                              \
+    } while (0)
+#define CZCHK(expr) do { cz_status _s = (expr); if (_s != CZ_OK) return _s; } while (0)
+
+// ------------------------------------------------------------------ small device helpers
+__global__ void synth_kernel(uint16_t* dst, size_t numel, uint64_t seed, uint32_t tid, float stdv, float mean) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < numel; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = cz_synth_bf16(seed, tid, i, stdv, mean);
+}
+__global__ void set_int_kernel(int* p, int v) { *p = v; }
+__global__ void fill_u32_kernel(uint32_t* p, uint32_t v, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+__global__ void init_out_ids_kernel(cz_dec_state* st, int n, uint32_t bos) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) st[i].out_ids[0] = bos;
+}
+// re-prime history of every stream: tok[b*hl + j] = out_ids_b[end - hl + j]  (src/main.rs:2533-2535)
+__global__ void gather_hist_kernel(const cz_dec_state* st, uint32_t* tok, int nstreams, int hl, unsigned long long end) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nstreams * hl) return;
+    const int b = i / hl, j = i % hl;
+    unsigned long long idx = end - hl + j;
+    const unsigned long long last = st[b].token_count;        // finished streams: clamp inside their buffer
+    if (idx > last) idx = last;
+    tok[i] = st[b].out_ids[idx];
+}
+
+cz_status DevBuf::ensure(size_t bytes) {
+    if (bytes <= cap) return CZ_OK;
+    if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(hipMalloc(&p, want));
+    cap = want;
+    return CZ_OK;
+}
+void DevBuf::release() { if (p) { hipError_t e = hipFree(p); (void)e; } p = nullptr; cap = 0; }
+
+// ------------------------------------------------------------------ profiling (HIP events on the session stream)
+void cz_session::prof_begin(int kind) {
+    if (!prof_on) return;
+    ProfEvt ev; ev.kind = kind; ev.flops = 0; ev.bytes = 0;
+    if (!evt_free.empty()) { ev.e0 = evt_free.back(); evt_free.pop_back(); ev.e1 = evt_free.back(); evt_free.pop_back(); }
+    else { hipEventCreate(&ev.e0); hipEventCreate(&ev.e1); }
+    hipEventRecord(ev.e0, stream);
+    evt_open = ev;
+}
+void cz_session::prof_end(double flops, double bytes) {
+    if (!prof_on) return;
+    hipEventRecord(evt_open.e1, stream);
+    evt_open.flops = flops; evt_open.bytes = bytes;
+    evts.push_back(evt_open);
+    if (evts.size() >= 8192) prof_drain();
+}
+void cz_session::prof_drain() {
+    if (evts.empty()) return;
+    hipStreamSynchronize(stream);
+    for (auto& ev : evts) {
+        float ms = 0; hipEventElapsedTime(&ms, ev.e0, ev.e1);
+        ProfAcc& a = acc[ev.kind];
+        a.launches += 1; a.ms += ms; a.flops += ev.flops; a.bytes += ev.bytes;
+        evt_free.push_back(ev.e0); evt_free.push_back(ev.e1);
+    }
+    evts.clear();
+}
+static const char* kProfNames[PK_COUNT] = {"gemm_bf16w_f32_mfma", "gemm_skinny_f32_mfma", "attention_f32_mfma", "rmsnorm", "rope",
+                                           "swiglu", "embed", "cdf_pairs", "decode_symbol", "rwkv7_step"};
+
+// ------------------------------------------------------------------ model construction
+static cz_status synth(cz_session* s, uint16_t* dst, const char* name, size_t numel, float stdv, float mean) {
+    hipLaunchKernelGGL(synth_kernel, dim3(1024), dim3(256), 0, s->stream, dst, numel, s->seed, cz_fnv1a32(name), stdv, mean);
+    HIPCHK(hipGetLastError());
+    return CZ_OK;
+}
+// copy a checkpoint tensor to the device as bf16 (BF16 verbatim; F32/F16 only when every value is bf16-exact)
+static cz_status load_tensor(cz_session* s, std::vector<std::unique_ptr<SafeTensorsFile>>& files, const std::string& name,
+                             uint16_t* dst, size_t numel) {
+    for (auto& f : files) {
+        auto it = f->tensors.find(name);
+        if (it == f->tensors.end()) continue;
+        const SafeTensor& t = it->second;
+        size_t n = 1; for (auto d : t.shape) n *= (size_t)d;
+        if (n != numel) { cz_set_error("tensor %s has %zu elements, expected %zu", name.c_str(), n, numel); return CZ_ERR_IO; }
+        if (t.dtype == "BF16") {
+            if (t.nbytes != numel * 2) { cz_set_error("tensor %s: byte size mismatch", name.c_str()); return CZ_ERR_IO; }
+            HIPCHK(hipMemcpy(dst, t.data, numel * 2, hipMemcpyHostToDevice));
+            return CZ_OK;
+        }
+        if (t.dtype == "F32") {
+            if (t.nbytes != numel * 4) { cz_set_error("tensor %s: byte size mismatch", name.c_str()); return CZ_ERR_IO; }
+            std::vector<uint16_t> tmp(numel);
+            const uint32_t* src = (const uint32_t*)t.data;
+            for (size_t i = 0; i < numel; ++i) {
+                uint32_t u; memcpy(&u, src + i, 4);
+                if (u & 0xffffu) { cz_set_error("tensor %s is F32 with values that are not bf16-representable (unsupported)", name.c_str()); return CZ_ERR_UNSUPPORTED; }
+                tmp[i] = (uint16_t)(u >> 16);
+            }
+            HIPCHK(hipMemcpy(dst, tmp.data(), numel * 2, hipMemcpyHostToDevice));
+            return CZ_OK;
+        }
+        cz_set_error("tensor %s has unsupported dtype %s", name.c_str(), t.dtype.c_str());
+        return CZ_ERR_UNSUPPORTED;
+    }
+    cz_set_error("tensor %s not found in the safetensors files", name.c_str());
+    return CZ_ERR_IO;
+}
+
+static cz_status read_file(const char* path, std::string* out) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { cz_set_error("failed reading %s", path); return CZ_ERR_IO; }
+    char buf[1 << 14]; size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out->append(buf, n);
+    fclose(f); return CZ_OK;
+}
+static cz_status parse_llama_config(const char* path, cz_llama_config* c) {     // HF config.json -> LlamaConfig (src/models.rs:49-53)
+    std::string txt; CZCHK(read_file(path, &txt));
+    JsonValue root; std::string err;
+    if (!cz_json_parse(txt.data(), txt.size(), &root, &err)) { cz_set_error("failed to parse config.json as HF LlamaConfig: %s", err.c_str()); return CZ_ERR_IO; }
+    auto num = [&](const char* k, double def) { const JsonValue* v = root.get(k); return v && v->kind == JsonValue::Num ? v->num : def; };
+    c->vocab = (int)num("vocab_size", 0); c->d_model = (int)num("hidden_size", 0); c->n_layers = (int)num("num_hidden_layers", 0);
+    c->n_heads = (int)num("num_attention_heads", 0); c->n_kv_heads = (int)num("num_key_value_heads", c->n_heads);
+    c->d_ffn = (int)num("intermediate_size", 0); c->max_pos = (int)num("max_position_embeddings", 2048);
+    c->rope_theta = (float)num("rope_theta", 10000.0); c->rms_eps = (float)num("rms_norm_eps", 1e-5);
+    return CZ_OK;
+}
+
+static cz_status build_llama(cz_session* s, const cz_model_desc* desc) {
+    LlamaModel& m = s->llama;
+    if (desc->config_path) CZCHK(parse_llama_config(desc->config_path, &m.cfg)); else m.cfg = desc->llama;
+    const cz_llama_config& c = m.cfg;
+    if (c.n_heads <= 0 || c.n_kv_heads <= 0 || c.d_model != c.n_heads * 64 || c.n_heads % c.n_kv_heads || 16 / (c.n_heads / c.n_kv_heads) < 1 ||
+        c.d_model % 64 || c.d_ffn % 64 || c.vocab % 64 || c.d_model > 1024 || c.n_layers <= 0 || (c.d_model + 2 * c.n_kv_heads * 64) % 64) {
+        cz_set_error("unsupported LLaMA shape (need head_dim 64, d_model/d_ffn/vocab multiples of 64, d_model <= 1024)");
+        return CZ_ERR_UNSUPPORTED;
+    }
+    const size_t d = c.d_model, kvd = (size_t)c.n_kv_heads * 64, f = c.d_ffn, V = c.vocab, L = c.n_layers;
+    const size_t per_layer = d + (d + 2 * kvd) * d + d * d + d + 2 * f * d + d * f;
+    const size_t total = V * d + L * per_layer + d;
+    HIPCHK(hipMalloc((void**)&m.blob, total * 2));
+    uint16_t* p = m.blob;
+    m.E = p; p += V * d;
+    m.L.resize(L);
+    for (size_t l = 0; l < L; ++l) {
+        LlamaModel::Layer& y = m.L[l];
+        y.ln1 = p; p += d; y.wqkv = p; p += (d + 2 * kvd) * d; y.wo = p; p += d * d; y.ln2 = p; p += d;
+        y.wgu = p; p += 2 * f * d; y.wd = p; p += d * f;
+    }
+    m.lnf = p; p += d;
+    m.param_count = V * d + L * ((d + 2 * kvd) * d + d * d + 2 * f * d + d * f);
+    std::vector<std::unique_ptr<SafeTensorsFile>> files;
+    const bool synthetic = desc->n_weight_paths == 0;
+    for (size_t i = 0; i < desc->n_weight_paths; ++i) {
+        files.emplace_back(new SafeTensorsFile());
+        if (!cz_safetensors_open(desc->weight_paths[i], files.back().get())) return CZ_ERR_IO;
+    }
+    auto get = [&](const std::string& name, uint16_t* dst, size_t numel, float stdv, float mean) -> cz_status {
+        return synthetic ? synth(s, dst, name.c_str(), numel, stdv, mean) : load_tensor(s, files, name, dst, numel);
+    };
+    CZCHK(get("model.embed_tokens.weight", m.E, V * d, desc->synthetic_embed_std, 0.0f));   // lm_head tied (tie_word_embeddings)
+    for (size_t l = 0; l < L; ++l) {
+        const std::string pre = "model.layers." + std::to_string(l) + ".";
+        LlamaModel::Layer& y = m.L[l];
+        CZCHK(get(pre + "input_layernorm.weight", y.ln1, d, 0.1f, 1.0f));
+        CZCHK(get(pre + "self_attn.q_proj.weight", y.wqkv, d * d, 0.02f, 0.0f));
+        CZCHK(get(pre + "self_attn.k_proj.weight", y.wqkv + d * d, kvd * d, 0.02f, 0.0f));
+        CZCHK(get(pre + "self_attn.v_proj.weight", y.wqkv + (d + kvd) * d, kvd * d, 0.02f, 0.0f));
+        CZCHK(get(pre + "self_attn.o_proj.weight", y.wo, d * d, 0.02f, 0.0f));
+        CZCHK(get(pre + "post_attention_layernorm.weight", y.ln2, d, 0.1f, 1.0f));
+        CZCHK(get(pre + "mlp.gate_proj.weight", y.wgu, f * d, 0.02f, 0.0f));
+        CZCHK(get(pre + "mlp.up_proj.weight", y.wgu + f * d, f * d, 0.02f, 0.0f));
+        CZCHK(get(pre + "mlp.down_proj.weight", y.wd, d * f, 0.02f, 0.0f));
+    }
+    CZCHK(get("model.norm.weight", m.lnf, d, 0.1f, 1.0f));
+    // RoPE tables (candle llama Cache::new): inv_freq_i = 1/theta^(2i/64) in f32, angle = pos * inv_freq (f32 product),
+    // cos/sin rounded from f64 libm (the reference's f32 libm is not reproducible across hosts)
+    const int mp = c.max_pos;
+    std::vector<float> hc((size_t)mp * 32), hs((size_t)mp * 32);
+    float inv[32];
+    for (int i = 0; i < 32; ++i) {
+        float e = (float)(2 * i) / 64.0f;
+        float pw = (float)pow((double)c.rope_theta, (double)e);
+        inv[i] = 1.0f / pw;
+    }
+    for (int pz = 0; pz < mp; ++pz)
+        for (int i = 0; i < 32; ++i) {
+            float a = (float)pz * inv[i];
+            hc[(size_t)pz * 32 + i] = (float)cos((double)a);
+            hs[(size_t)pz * 32 + i] = (float)sin((double)a);
+        }
+    HIPCHK(hipMalloc((void**)&m.rope_cos, hc.size() * 4));
+    HIPCHK(hipMalloc((void**)&m.rope_sin, hs.size() * 4));
+    HIPCHK(hipMemcpy(m.rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m.rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return CZ_OK;
+}
+
+// ------------------------------------------------------------------ the transformer body over M packed rows
+// tokens are in s->tok; on return s->x holds the residual stream [M][d].
+static cz_status llama_body(cz_session* s, int M, const cz_seq_desc* seqd, const cz_rope_desc* roped, int nseq, int max_rows,
+                            int max_nk, size_t kv_layer_stride, const int* pos_dev) {
+    const LlamaModel& m = s->llama; const cz_llama_config& c = m.cfg;
+    const int d = c.d_model, kvd = c.n_kv_heads * 64, f = c.d_ffn, nq = d + 2 * kvd;
+    CZCHK(s->x.ensure((size_t)M * d * 4)); CZCHK(s->xn.ensure((size_t)M * d * 4));
+    CZCHK(s->qkv.ensure((size_t)M * nq * 4)); CZCHK(s->gu.ensure((size_t)M * 2 * f * 4)); CZCHK(s->h.ensure((size_t)M * f * 4));
+    float *x = (float*)s->x.p, *xn = (float*)s->xn.p, *qkv = (float*)s->qkv.p, *gu = (float*)s->gu.p, *h = (float*)s->h.p;
+    hipStream_t st = s->stream;
+    const int big = s->force_big_gemm;
+    auto gemm = [&](const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R, int N, int K) -> hipError_t {
+        s->prof_begin(M <= 64 && !big ? PK_GEMM_SKINNY : PK_GEMM);
+        hipError_t e = cz_launch_gemm(st, A, lda, W, C, ldc, R, ldc, M, N, K, big);
+        s->prof_end(2.0 * M * (double)N * K, (double)N * K * 2 + (double)M * (N + K) * 4);
+        return e;
+    };
+    s->prof_begin(PK_EMBED);
+    HIPCHK(cz_launch_embed(st, (const uint32_t*)s->tok.p, m.E, x, M, d));
+    s->prof_end(0, (double)M * d * 6);
+    for (int l = 0; l < c.n_layers; ++l) {
+        const LlamaModel::Layer& y = m.L[l];
+        s->prof_begin(PK_RMSNORM); HIPCHK(cz_launch_rmsnorm(st, x, d, y.ln1, xn, d, M, d, c.rms_eps, nullptr)); s->prof_end(0, (double)M * d * 8);
+        HIPCHK(gemm(xn, d, y.wqkv, qkv, nq, nullptr, nq, d));
+        s->prof_begin(PK_ROPE);
+        HIPCHK(cz_launch_rope(st, qkv, nq, roped, nseq, max_rows, c.n_heads, c.n_kv_heads, m.rope_cos, m.rope_sin, (size_t)l * kv_layer_stride, pos_dev));
+        s->prof_end(0, (double)M * nq * 8);
+        s->prof_begin(PK_ATTN);
+        HIPCHK(cz_launch_attention(st, qkv, nq, xn, d, seqd, nseq, max_rows, max_nk, c.n_heads, c.n_kv_heads, (size_t)l * kv_layer_stride, pos_dev));
+        s->prof_end(4.0 * 64 * c.n_heads * (double)M * max_nk * 0.5, 0);
+        HIPCHK(gemm(xn, d, y.wo, x, d, x, d, d));                           // x = attn_out . Wo^T + x
+        s->prof_begin(PK_RMSNORM); HIPCHK(cz_launch_rmsnorm(st, x, d, y.ln2, xn, d, M, d, c.rms_eps, nullptr)); s->prof_end(0, (double)M * d * 8);
+        HIPCHK(gemm(xn, d, y.wgu, gu, 2 * f, nullptr, 2 * f, d));
+        s->prof_begin(PK_SWIGLU); HIPCHK(cz_launch_swiglu(st, gu, h, M, f)); s->prof_end(0, (double)M * f * 12);
+        HIPCHK(gemm(h, f, y.wd, x, d, x, d, f));                            // x = mlp_out + x
+    }
+    return CZ_OK;
+}
+
+// final norm on selected rows + tied lm_head: logits[r][:] for r in [0, nrows) from residual rows row_index[r]
+static cz_status llama_head(cz_session* s, const int* row_index_dev, int nrows, float* logits) {
+    const LlamaModel& m = s->llama; const cz_llama_config& c = m.cfg;
+    const int d = c.d_model;
+    CZCHK(s->xl.ensure((size_t)nrows * d * 4));
+    s->prof_begin(PK_RMSNORM);
+    HIPCHK(cz_launch_rmsnorm(s->stream, (const float*)s->x.p, d, m.lnf, (float*)s->xl.p, d, nrows, d, c.rms_eps, row_index_dev));
+    s->prof_end(0, (double)nrows * d * 8);
+    const int big = s->force_big_gemm;
+    s->prof_begin(nrows <= 64 && !big ? PK_GEMM_SKINNY : PK_GEMM);
+    HIPCHK(cz_launch_gemm(s->stream, (const float*)s->xl.p, d, m.E, logits, c.vocab, nullptr, 0, nrows, c.vocab, d, big));
+    s->prof_end(2.0 * nrows * (double)c.vocab * d, (double)c.vocab * d * 2 + (double)nrows * (c.vocab + d) * 4);
+    return CZ_OK;
+}
+
+// ------------------------------------------------------------------ lock-step streams (KV cache resident in HBM)
+static cz_status ensure_streams(cz_session* s, int B) {
+    const cz_llama_config& c = s->llama.cfg;
+    const size_t kvd = (size_t)c.n_kv_heads * 64;
+    if (B > s->max_streams) { cz_set_error("%d streams exceed max_streams = %d", B, s->max_streams); return CZ_ERR_ARG; }
+    if (!s->kvcache) {
+        s->ctx_cap = CZ_MAX_CTX;
+        s->kv_layer_stride = 2 * s->ctx_cap * kvd;
+        s->kv_stream_stride = (size_t)c.n_layers * s->kv_layer_stride;
+        HIPCHK(hipMalloc((void**)&s->kvcache, (size_t)s->max_streams * s->kv_stream_stride * 4));
+        HIPCHK(hipMalloc((void**)&s->pos_dev, 64));
+        std::vector<cz_seq_desc> sd(s->max_streams); std::vector<cz_rope_desc> rd(s->max_streams);
+        for (int b = 0; b < s->max_streams; ++b) {
+            float* kb = s->kvcache + (size_t)b * s->kv_stream_stride;
+            sd[b] = {b, 1, 0, (int)kvd, kb, kb + s->ctx_cap * kvd};
+            rd[b] = {b, 1, 0, (int)kvd, kb, kb + s->ctx_cap * kvd};
+        }
+        HIPCHK(hipMalloc((void**)&s->step_seqd, sd.size() * sizeof(cz_seq_desc)));
+        HIPCHK(hipMalloc((void**)&s->step_roped, rd.size() * sizeof(cz_rope_desc)));
+        HIPCHK(hipMemcpy(s->step_seqd, sd.data(), sd.size() * sizeof(cz_seq_desc), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(s->step_roped, rd.data(), rd.size() * sizeof(cz_rope_desc), hipMemcpyHostToDevice));
+        std::vector<int> ri(s->max_streams); for (int b = 0; b < s->max_streams; ++b) ri[b] = b;
+        HIPCHK(hipMalloc((void**)&s->step_rows, ri.size() * 4));
+        HIPCHK(hipMemcpy(s->step_rows, ri.data(), ri.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&s->step_logits, (size_t)s->max_streams * c.vocab * 4));
+        HIPCHK(hipMalloc((void**)&s->step_sym, (size_t)s->max_streams * 4));
+    }
+    return CZ_OK;
+}
+// one token per stream at position `pos` (tokens in s->tok[0..B)); logits -> s->step_logits [B][V]
+static cz_status llama_step(cz_session* s, int B, int pos) {
+    if (pos >= CZ_MAX_CTX || pos >= s->llama.cfg.max_pos) { cz_set_error("position %d exceeds the supported context (%d)", pos, CZ_MAX_CTX); return CZ_ERR_STATE; }
+    hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, pos);
+    CZCHK(llama_body(s, B, s->step_seqd, s->step_roped, B, 1, pos + 1, s->kv_layer_stride, s->pos_dev));
+    return llama_head(s, s->step_rows, B, s->step_logits);
+}
+// re-prime: every stream forwards hl tokens (s->tok[b*hl + j]) at positions 0..hl-1 into its cache; logits of the last row
+static cz_status llama_reprime(cz_session* s, int B, int hl) {
+    if (hl <= 0 || hl > CZ_MAX_CTX) { cz_set_error("history length %d out of range", hl); return CZ_ERR_ARG; }
+    const size_t kvd = (size_t)s->llama.cfg.n_kv_heads * 64;
+    std::vector<cz_seq_desc> sd(B); std::vector<cz_rope_desc> rd(B); std::vector<int> ri(B);
+    for (int b = 0; b < B; ++b) {
+        float* kb = s->kvcache + (size_t)b * s->kv_stream_stride;
+        sd[b] = {b * hl, hl, 0, (int)kvd, kb, kb + s->ctx_cap * kvd};
+        rd[b] = {b * hl, hl, 0, (int)kvd, kb, kb + s->ctx_cap * kvd};
+        ri[b] = b * hl + hl - 1;
+    }
+    CZCHK(s->seqd.ensure(sd.size() * sizeof(cz_seq_desc))); CZCHK(s->roped.ensure(rd.size() * sizeof(cz_rope_desc)));
+    CZCHK(s->rowidx.ensure(ri.size() * 4));
+    HIPCHK(hipMemcpyAsync(s->seqd.p, sd.data(), sd.size() * sizeof(cz_seq_desc), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->roped.p, rd.data(), rd.size() * sizeof(cz_rope_desc), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->rowidx.p, ri.data(), ri.size() * 4, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));       // host vectors go out of scope
+    CZCHK(llama_body(s, B * hl, (const cz_seq_desc*)s->seqd.p, (const cz_rope_desc*)s->roped.p, B, hl, hl, s->kv_layer_stride, nullptr));
+    return llama_head(s, (const int*)s->rowidx.p, B, s->step_logits);
+}
+
+// ------------------------------------------------------------------ schedule (the reference's re-prime predicate)
+struct Seg { int stream; size_t hist_start, start_i, end_i; };   // rows = ids[hist_start .. end_i), coded i in [start_i, end_i)
+static void plan_segments(int stream, size_t n_ids, uint32_t context, uint32_t R, std::vector<Seg>* out) {
+    if (n_ids < 2) return;
+    const size_t ec = context < 511 ? context : 511;            // src/main.rs:1935
+    size_t index_pos = 1, seg_start = 0, hist_start = 0;        // after step(BOS) (src/main.rs:1916)
+    for (size_t i = 0; i + 1 < n_ids; ++i) {
+        if (index_pos >= ec && R != 0 && (i % R) == 0 && i > 0) {   // src/main.rs:2280
+            out->push_back({stream, hist_start, seg_start, i});
+            const size_t end = 1 + i;
+            hist_start = end > ec ? end - ec : 0;               // :2281-2283
+            seg_start = i; index_pos = end - hist_start;
+        }
+        index_pos += 1;                                          // step(sym) (:2345)
+    }
+    out->push_back({stream, hist_start, seg_start, n_ids - 1});
+}
+
+// ------------------------------------------------------------------ encode
+static cz_status encode_llama(cz_session* s, size_t n_streams, const uint32_t* const* ids, const size_t* n, uint32_t context,
+                              uint32_t R, uint32_t* const* out_lo, uint32_t* const* out_hi) {
+    const cz_llama_config& c = s->llama.cfg;
+    if (R == 0) { cz_set_error("reprime_interval must be > 0"); return CZ_ERR_ARG; }       // the reference would panic on i % 0
+    std::vector<Seg> segs;
+    for (size_t st = 0; st < n_streams; ++st) {
+        if (n[st] == 0) { cz_set_error("stream %zu is empty (ids must start with BOS)", st); return CZ_ERR_ARG; }
+        for (size_t i = 0; i < n[st]; ++i) if (ids[st][i] >= (uint32_t)c.vocab) { cz_set_error("token id %u >= vocab %d", ids[st][i], c.vocab); return CZ_ERR_ARG; }
+        plan_segments((int)st, n[st], context, R, &segs);
+    }
+    for (auto& sg : segs) {
+        size_t T = sg.end_i - sg.hist_start;
+        if (T > (size_t)CZ_MAX_CTX || T > (size_t)c.max_pos) { cz_set_error("segment of %zu positions exceeds the supported context (%d)", T, CZ_MAX_CTX); return CZ_ERR_STATE; }
+    }
+    const int d = c.d_model, kvd = c.n_kv_heads * 64, nq = d + 2 * kvd;
+    size_t si = 0;
+    while (si < segs.size()) {
+        // pack segments into one batch
+        size_t M = 0, sj = si; int max_rows = 0;
+        while (sj < segs.size()) {
+            size_t T = segs[sj].end_i - segs[sj].hist_start;
+            if (M && M + T > s->max_batch_rows) break;
+            M += T; max_rows = std::max(max_rows, (int)T); ++sj;
+        }
+        const int nseq = (int)(sj - si);
+        std::vector<uint32_t> tok(M), sym; std::vector<int> rowidx; std::vector<cz_seq_desc> sd(nseq); std::vector<cz_rope_desc> rd(nseq);
+        struct Dst { int stream; size_t i; }; std::vector<Dst> dst;
+        CZCHK(s->qkv.ensure(M * (size_t)nq * 4));
+        float* qkv = (float*)s->qkv.p;
+        size_t row = 0;
+        for (int q = 0; q < nseq; ++q) {
+            const Seg& sg = segs[si + q];
+            const size_t T = sg.end_i - sg.hist_start;
+            const uint32_t* src = ids[sg.stream];
+            for (size_t p = 0; p < T; ++p) tok[row + p] = src[sg.hist_start + p];
+            float* kb = qkv + row * nq + d;                     // K/V stay in place inside the fused QKV rows
+            sd[q] = {(int)row, (int)T, 0, nq, kb, kb + kvd};
+            rd[q] = {(int)row, (int)T, 0, nq, kb, kb + kvd};
+            for (size_t i = sg.start_i; i < sg.end_i; ++i) {
+                rowidx.push_back((int)(row + (i - sg.hist_start)));
+                sym.push_back(src[i + 1]);
+                dst.push_back({sg.stream, i});
+            }
+            row += T;
+        }
+        const size_t Lr = rowidx.size();
+        CZCHK(s->tok.ensure(M * 4)); CZCHK(s->seqd.ensure(nseq * sizeof(cz_seq_desc))); CZCHK(s->roped.ensure(nseq * sizeof(cz_rope_desc)));
+        CZCHK(s->rowidx.ensure(Lr * 4)); CZCHK(s->sym.ensure(Lr * 4)); CZCHK(s->clo.ensure(Lr * 4)); CZCHK(s->chi.ensure(Lr * 4));
+        HIPCHK(hipMemcpyAsync(s->tok.p, tok.data(), M * 4, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->seqd.p, sd.data(), nseq * sizeof(cz_seq_desc), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->roped.p, rd.data(), nseq * sizeof(cz_rope_desc), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->rowidx.p, rowidx.data(), Lr * 4, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->sym.p, sym.data(), Lr * 4, hipMemcpyHostToDevice, s->stream));
+        CZCHK(llama_body(s, (int)M, (const cz_seq_desc*)s->seqd.p, (const cz_rope_desc*)s->roped.p, nseq, max_rows, max_rows, 0, nullptr));
+        const size_t LB = s->logit_batch_rows;
+        CZCHK(s->logits.ensure(std::min(LB, Lr) * (size_t)c.vocab * 4));
+        for (size_t r0 = 0; r0 < Lr; r0 += LB) {
+            const int nr = (int)std::min(LB, Lr - r0);
+            CZCHK(llama_head(s, (const int*)s->rowidx.p + r0, nr, (float*)s->logits.p));
+            s->prof_begin(PK_CDF);
+            HIPCHK(cz_launch_cdf_pairs(s->stream, (const float*)s->logits.p, c.vocab, (const uint32_t*)s->sym.p + r0, (uint32_t*)s->clo.p + r0,
+                                       (uint32_t*)s->chi.p + r0, nr, c.vocab, 0));
+            s->prof_end(0, (double)nr * c.vocab * 4);
+        }
+        std::vector<uint32_t> lo(Lr), hi(Lr);
+        HIPCHK(hipMemcpyAsync(lo.data(), s->clo.p, Lr * 4, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(hi.data(), s->chi.p, Lr * 4, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        for (size_t r = 0; r < Lr; ++r) { out_lo[dst[r].stream][dst[r].i] = lo[r]; out_hi[dst[r].stream][dst[r].i] = hi[r]; }
+        si = sj;
+    }
+    return CZ_OK;
+}
+
+// ------------------------------------------------------------------ decode (lock-step)
+static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs,
+                                    uint32_t context_window, uint32_t R, uint32_t bos, uint32_t* const* out_ids) {
+    const cz_llama_config& c = s->llama.cfg;
+    if (R == 0) { cz_set_error("reprime_interval must be > 0"); return CZ_ERR_ARG; }
+    if (bos >= (uint32_t)c.vocab) { cz_set_error("bos id %u >= vocab", bos); return CZ_ERR_ARG; }
+    CZCHK(ensure_streams(s, B));
+    size_t pay_total = 0, ids_total = 0, max_tc = 0;
+    for (int b = 0; b < B; ++b) { pay_total += lens[b] + 16; ids_total += tcs[b] + 1; max_tc = std::max(max_tc, tcs[b]); }
+    CZCHK(s->payload.ensure(pay_total)); CZCHK(s->outids.ensure(ids_total * 4)); CZCHK(s->decst.ensure(B * sizeof(cz_dec_state)));
+    std::vector<cz_dec_state> hs(B); std::vector<uint8_t> pay(pay_total, 0);
+    size_t po = 0, io = 0;
+    for (int b = 0; b < B; ++b) {
+        if (lens[b]) memcpy(pay.data() + po, payloads[b], lens[b]);
+        cz_dec_state d; memset(&d, 0, sizeof d);
+        d.in = (const uint8_t*)s->payload.p + po; d.in_len = lens[b]; d.out_ids = (uint32_t*)s->outids.p + io; d.token_count = tcs[b];
+        d.active = tcs[b] > 0;
+        hs[b] = d; po += lens[b] + 16; io += tcs[b] + 1;
+    }
+    HIPCHK(hipMemcpyAsync(s->payload.p, pay.data(), pay_total, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->decst.p, hs.data(), B * sizeof(cz_dec_state), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    cz_dec_state* dst = (cz_dec_state*)s->decst.p;
+    HIPCHK(cz_launch_dec_init(s->stream, dst, B));                                           // ArithmeticDecoder::new (:2485)
+    hipLaunchKernelGGL(init_out_ids_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, dst, B, bos);
+    CZCHK(s->tok.ensure((size_t)B * CZ_MAX_CTX * 4));
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, (uint32_t*)s->tok.p, bos, B);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, s->step_sym, bos, B);   // finished streams keep a valid id
+    s->index_pos = 0;                                                                        // the single-stream step state is reset
+    CZCHK(llama_step(s, B, 0));                                                              // step(bos) (:2485)
+    size_t index_pos = 1;
+    size_t ec = context_window > 0 ? context_window - 1 : 0; if (ec > 511) ec = 511;         // :2506
+    for (size_t i = 0; i < max_tc; ++i) {
+        if (index_pos >= ec && (i % R) == 0 && i > 0) {                                      // :2532
+            const size_t end = i + 1, hl = end > ec ? ec : end;                              // out_tokens.len() == i + 1
+            if (hl == 0) { cz_set_error("reprime called with empty history"); return CZ_ERR_STATE; }
+            hipLaunchKernelGGL(gather_hist_kernel, dim3((unsigned)((B * hl + 255) / 256)), dim3(256), 0, s->stream, dst, (uint32_t*)s->tok.p, B, (int)hl,
+                               (unsigned long long)end);
+            CZCHK(llama_reprime(s, B, (int)hl));
+            index_pos = hl;
+        }
+        s->prof_begin(PK_DECODE);
+        HIPCHK(cz_launch_decode_symbol(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, (unsigned long long)i));
+        s->prof_end(0, (double)B * c.vocab * 4);
+        if (i + 1 < max_tc) {
+            // the reference also steps after the last symbol (:2627); its logits are never used, so it is skipped here
+            HIPCHK(hipMemcpyAsync(s->tok.p, s->step_sym, (size_t)B * 4, hipMemcpyDeviceToDevice, s->stream));
+            CZCHK(llama_step(s, B, (int)index_pos));
+        }
+        index_pos += 1;
+    }
+    std::vector<uint32_t> all(ids_total);
+    HIPCHK(hipMemcpyAsync(all.data(), s->outids.p, ids_total * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    io = 0;
+    for (int b = 0; b < B; ++b) { memcpy(out_ids[b], all.data() + io, (tcs[b] + 1) * 4); if (tcs[b] == 0) out_ids[b][0] = bos; io += tcs[b] + 1; }
+    return CZ_OK;
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" cz_status cz_session_open(const cz_model_desc* desc, int device_ordinal, cz_session** out) {
+    if (!desc || !out) { cz_set_error("cz_session_open: null argument"); return CZ_ERR_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { cz_set_error("no HIP device available (this library has no CPU fallback)"); return CZ_ERR_HIP; }
+    if (device_ordinal < 0 || device_ordinal >= ndev) { cz_set_error("device ordinal %d out of range (%d devices)", device_ordinal, ndev); return CZ_ERR_ARG; }
+    HIPCHK(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device_ordinal));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { cz_set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device_ordinal, prop.gcnArchName); return CZ_ERR_HIP; }
+    cz_session* s = new cz_session();
+    s->backend = desc->backend; s->device = device_ordinal; s->seed = desc->synthetic_seed;
+    s->max_streams = desc->max_streams ? (int)desc->max_streams : 64;
+    if (s->max_streams > 64) { delete s; cz_set_error("max_streams > 64 is not supported"); return CZ_ERR_ARG; }
+    hipError_t e = hipStreamCreate(&s->stream);
+    if (e != hipSuccess) { delete s; cz_set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return CZ_ERR_HIP; }
+    cz_status rc = CZ_OK;
+    if (desc->backend == CZ_BACKEND_SMOLLM) rc = build_llama(s, desc);
+    else if (desc->backend == CZ_BACKEND_RWKV7) rc = cz_rwkv7_build(s, desc);
+    else { cz_set_error("unknown backend %d", (int)desc->backend); rc = CZ_ERR_ARG; }      // src/main.rs:1829 "unknown backend"
+    if (rc == CZ_OK && cz_attention_prepare(CZ_MAX_CTX) != hipSuccess) { cz_set_error("cannot reserve LDS for attention"); rc = CZ_ERR_HIP; }
+    if (rc != CZ_OK) { cz_session_close(s); return rc; }
+    *out = s;
+    return CZ_OK;
+}
+extern "C" void cz_session_close(cz_session* s) {
+    if (!s) return;
+    hipSetDevice(s->device);
+    if (s->stream) hipStreamSynchronize(s->stream);
+    s->prof_drain();
+    for (auto e : s->evt_free) hipEventDestroy(e);
+    DevBuf* bufs[] = {&s->tok, &s->x, &s->xn, &s->qkv, &s->gu, &s->h, &s->seqd, &s->roped, &s->rowidx, &s->sym, &s->clo, &s->chi, &s->xl,
+                      &s->logits, &s->payload, &s->outids, &s->decst};
+    for (auto b : bufs) b->release();
+    void* ptrs[] = {s->llama.blob, s->llama.rope_cos, s->llama.rope_sin, s->kvcache, s->pos_dev, s->step_seqd, s->step_roped, s->step_rows,
+                    s->step_logits, s->step_sym};
+    for (auto p : ptrs) if (p) { hipError_t e = hipFree(p); (void)e; }
+    cz_rwkv7_destroy(s);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+}
+extern "C" size_t cz_vocab_size(const cz_session* s) { return s ? (s->backend == CZ_BACKEND_SMOLLM ? (size_t)s->llama.cfg.vocab : cz_rwkv7_vocab(s)) : 0; }
+extern "C" size_t cz_max_context_length(const cz_session* s) { return s && s->backend == CZ_BACKEND_SMOLLM ? 512 : (size_t)-1; }   // src/models.rs:91, :149
+extern "C" size_t cz_index_pos(const cz_session* s) { return s ? s->index_pos : 0; }
+
+extern "C" cz_status cz_step_logits(cz_session* s, uint32_t token, float* out_logits) {
+    if (!s || !out_logits) { cz_set_error("cz_step_logits: null argument"); return CZ_ERR_ARG; }
+    HIPCHK(hipSetDevice(s->device));
+    if (s->backend == CZ_BACKEND_RWKV7) return cz_rwkv7_step_host(s, token, out_logits);
+    if (token >= (uint32_t)s->llama.cfg.vocab) { cz_set_error("token id %u >= vocab %d", token, s->llama.cfg.vocab); return CZ_ERR_ARG; }
+    CZCHK(ensure_streams(s, 1));
+    CZCHK(s->tok.ensure(64));
+    HIPCHK(hipMemcpyAsync(s->tok.p, &token, 4, hipMemcpyHostToDevice, s->stream));
+    CZCHK(llama_step(s, 1, (int)s->index_pos));
+    HIPCHK(hipMemcpyAsync(out_logits, s->step_logits, (size_t)s->llama.cfg.vocab * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->index_pos += 1;                                                                      // src/models.rs:95
+    return CZ_OK;
+}
+extern "C" cz_status cz_reprime_logits(cz_session* s, const uint32_t* history, size_t n, float* out_logits) {
+    if (!s || !out_logits) { cz_set_error("cz_reprime_logits: null argument"); return CZ_ERR_ARG; }
+    if (!history || n == 0) { cz_set_error("reprime called with empty history"); return CZ_ERR_ARG; }   // src/models.rs:108 / :164
+    HIPCHK(hipSetDevice(s->device));
+    if (s->backend == CZ_BACKEND_RWKV7) return cz_rwkv7_reprime_host(s, history, n, out_logits);
+    for (size_t i = 0; i < n; ++i) if (history[i] >= (uint32_t)s->llama.cfg.vocab) { cz_set_error("token id %u >= vocab", history[i]); return CZ_ERR_ARG; }
+    if (n > (size_t)CZ_MAX_CTX) { cz_set_error("history of %zu tokens exceeds the supported context (%d)", n, CZ_MAX_CTX); return CZ_ERR_STATE; }
+    CZCHK(ensure_streams(s, 1));
+    CZCHK(s->tok.ensure(n * 4));
+    HIPCHK(hipMemcpyAsync(s->tok.p, history, n * 4, hipMemcpyHostToDevice, s->stream));
+    s->index_pos = 0;                                                                       // fresh cache (src/models.rs:105-107)
+    CZCHK(llama_reprime(s, 1, (int)n));
+    HIPCHK(hipMemcpyAsync(out_logits, s->step_logits, (size_t)s->llama.cfg.vocab * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->index_pos = n;                                                                       // src/models.rs:111
+    return CZ_OK;
+}
+
+extern "C" cz_status cz_encode_tokens_batch(cz_session* s, size_t n_streams, const uint32_t* const* ids, const size_t* n, uint32_t context,
+                                            uint32_t reprime_interval, uint32_t* const* out_c_lo, uint32_t* const* out_c_hi) {
+    if (!s || !ids || !n || !out_c_lo || !out_c_hi) { cz_set_error("cz_encode_tokens_batch: null argument"); return CZ_ERR_ARG; }
+    HIPCHK(hipSetDevice(s->device));
+    if (s->backend == CZ_BACKEND_RWKV7) return cz_rwkv7_encode(s, n_streams, ids, n, out_c_lo, out_c_hi);
+    return encode_llama(s, n_streams, ids, n, context, reprime_interval, out_c_lo, out_c_hi);
+}
+extern "C" cz_status cz_encode_tokens(cz_session* s, const uint32_t* ids, size_t n, uint32_t context, uint32_t reprime_interval,
+                                      uint32_t* out_c_lo, uint32_t* out_c_hi) {
+    return cz_encode_tokens_batch(s, 1, &ids, &n, context, reprime_interval, &out_c_lo, &out_c_hi);
+}
+extern "C" cz_status cz_decode_tokens_batch(cz_session* s, size_t n_streams, const uint8_t* const* payloads, const size_t* lens,
+                                            const size_t* token_counts, uint32_t context_window, uint32_t reprime_interval, uint32_t bos,
+                                            uint32_t* const* out_ids) {
+    if (!s || !payloads || !lens || !token_counts || !out_ids) { cz_set_error("cz_decode_tokens_batch: null argument"); return CZ_ERR_ARG; }
+    HIPCHK(hipSetDevice(s->device));
+    for (size_t g = 0; g < n_streams; g += (size_t)s->max_streams) {
+        const int B = (int)std::min((size_t)s->max_streams, n_streams - g);
+        if (s->backend == CZ_BACKEND_RWKV7) CZCHK(cz_rwkv7_decode_group(s, B, payloads + g, lens + g, token_counts + g, bos, out_ids + g));
+        else CZCHK(decode_llama_group(s, B, payloads + g, lens + g, token_counts + g, context_window, reprime_interval, bos, out_ids + g));
+    }
+    return CZ_OK;
+}
+extern "C" cz_status cz_decode_tokens(cz_session* s, const uint8_t* payload, size_t len, size_t token_count, uint32_t context_window,
+                                      uint32_t reprime_interval, uint32_t bos, uint32_t* out_ids) {
+    return cz_decode_tokens_batch(s, 1, &payload, &len, &token_count, context_window, reprime_interval, bos, &out_ids);
+}
+
+extern "C" cz_status cz_profile_enable(cz_session* s, int on) {
+    if (!s) return CZ_ERR_ARG;
+    s->prof_drain();
+    for (int k = 0; k < PK_COUNT; ++k) s->acc[k] = ProfAcc();
+    s->prof_on = on != 0;
+    return CZ_OK;
+}
+extern "C" cz_status cz_profile_read(cz_session* s, cz_kernel_stat* out, size_t cap, size_t* n) {
+    if (!s || !n) return CZ_ERR_ARG;
+    s->prof_drain();
+    size_t k = 0;
+    for (int i = 0; i < PK_COUNT; ++i) {
+        if (!s->acc[i].launches) continue;
+        if (k < cap && out) {
+            memset(&out[k], 0, sizeof out[k]);
+            snprintf(out[k].name, sizeof out[k].name, "%s", kProfNames[i]);
+            out[k].launches = s->acc[i].launches; out[k].total_ms = s->acc[i].ms; out[k].flops = s->acc[i].flops; out[k].bytes = s->acc[i].bytes;
+        }
+        ++k;
+    }
+    *n = k;
+    return CZ_OK;
+}
+extern "C" cz_status cz_synchronize(cz_session* s) {
+    if (!s) return CZ_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return CZ_OK;
+}
+// test/bench knobs (not part of the drop-in surface): 0 = default kernels
+extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
+    if (!s || !key) return CZ_ERR_ARG;
+    if (!strcmp(key, "force_big_gemm")) s->force_big_gemm = (int)value;
+    else if (!strcmp(key, "max_batch_rows")) s->max_batch_rows = (size_t)value;
+    else if (!strcmp(key, "logit_batch_rows")) s->logit_batch_rows = (size_t)value;
+    else { cz_set_error("unknown debug key %s", key); return CZ_ERR_ARG; }
+    return CZ_OK;
+}

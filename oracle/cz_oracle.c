@@ -838,3 +838,33 @@ int czo_smollm_decode_tokens(czo_smollm* s, const uint8_t* payload, size_t len, 
     free(logits); free(cdf);
     return 0;
 }
+
+
+/* ======================================================================================
+ * per-op entry points for kernel-level parity tests (same code paths as the model above)
+ * ====================================================================================== */
+void czo_gemm_bf16(const float* A, const uint16_t* W, const float* R, float* C, int M, int N, int K) {
+    packed_w pw; czo_pack_weights(&pw, W, N, K);
+    czo_gemm_canon(A, K, &pw, C, N, M);
+    if (R) for (size_t i = 0; i < (size_t)M * N; ++i) C[i] = C[i] + R[i];
+    free(pw.p);
+}
+void czo_rmsnorm_bf16w(const float* X, const uint16_t* w, float* Y, int M, int d, float eps) {
+    float* wf = widen(w, d);
+    rms_norm_rows(X, wf, Y, M, d, eps);
+    free(wf);
+}
+/* rows at positions pos0.. attend to K/V rows [0, pos0 + m]; Q [M][nh*64], K/V [nk][nkv*64], O [M][nh*64] */
+void czo_attention_ref(const float* Q, const float* K, const float* V, float* O, int M, int pos0, int nh, int nkv) {
+    czo_smollm s; memset(&s, 0, sizeof s);
+    s.cfg.n_heads = nh; s.cfg.n_kv_heads = nkv;
+    float* kc = (float*)K; float* vc = (float*)V;
+    s.kc = &kc; s.vc = &vc;
+    attention_rows(&s, 0, Q, O, M, (size_t)pos0);
+}
+void czo_swiglu(const float* GU, float* H, int M, int f) {
+    for (int m = 0; m < M; ++m) for (int j = 0; j < f; ++j) {
+        float g = GU[(size_t)m * 2 * f + j], u = GU[(size_t)m * 2 * f + f + j];
+        H[(size_t)m * f + j] = (g / (1.0f + czo_expf(-g))) * u;
+    }
+}

@@ -157,6 +157,12 @@ void czo_blake3_final16(czo_blake3* h, uint8_t out[16]);
 void czo_blake3_free(czo_blake3* h);
 void czo_blake3_bytes_bin16(const uint8_t* p, size_t n, uint8_t out[16]);
 
+/* per-op entry points for kernel-level parity tests */
+void czo_gemm_bf16(const float* A, const uint16_t* W, const float* R, float* C, int M, int N, int K);
+void czo_rmsnorm_bf16w(const float* X, const uint16_t* w, float* Y, int M, int d, float eps);
+void czo_attention_ref(const float* Q, const float* K, const float* V, float* O, int M, int pos0, int nh, int nkv);
+void czo_swiglu(const float* GU, float* H, int M, int f);
+
 int czo_num_threads(void);
 
 #ifdef __cplusplus

@@ -89,6 +89,10 @@ def lib():
         "czo_blake3_new": (vp, []), "czo_blake3_update": (None, [vp, vp, sz]), "czo_blake3_final16": (None, [vp, vp]),
         "czo_blake3_free": (None, [vp]), "czo_blake3_bytes_bin16": (None, [vp, sz, vp]),
         "czo_num_threads": (C.c_int, []),
+        "czo_gemm_bf16": (None, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
+        "czo_rmsnorm_bf16w": (None, [vp, vp, vp, C.c_int, C.c_int, f32]),
+        "czo_attention_ref": (None, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "czo_swiglu": (None, [vp, vp, C.c_int, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -365,3 +369,33 @@ class Rwkv7Session:
         rc = lib().czo_rwkv7_decode_tokens(self.h, _p(buf), len(payload), token_count, bos, _p(out))
         assert rc == 0
         return out
+
+
+# ---------------------------------------------------------------- per-op references (kernel-level parity tests)
+def gemm_bf16(A, W_bf16, R=None):
+    A = np.ascontiguousarray(A, np.float32); W_bf16 = np.ascontiguousarray(W_bf16, np.uint16)
+    M, K = A.shape; N = W_bf16.shape[0]
+    C_ = np.empty((M, N), np.float32)
+    Rr = np.ascontiguousarray(R, np.float32) if R is not None else None
+    lib().czo_gemm_bf16(_p(A), _p(W_bf16), _p(Rr), _p(C_), M, N, K)
+    return C_
+
+
+def rmsnorm_bf16w(X, w_bf16, eps=1e-5):
+    X = np.ascontiguousarray(X, np.float32); w_bf16 = np.ascontiguousarray(w_bf16, np.uint16)
+    Y = np.empty_like(X)
+    lib().czo_rmsnorm_bf16w(_p(X), _p(w_bf16), _p(Y), X.shape[0], X.shape[1], eps)
+    return Y
+
+
+def attention_ref(Q, K, V, pos0, nh, nkv):
+    Q = np.ascontiguousarray(Q, np.float32); K = np.ascontiguousarray(K, np.float32); V = np.ascontiguousarray(V, np.float32)
+    O = np.empty_like(Q)
+    lib().czo_attention_ref(_p(Q), _p(K), _p(V), _p(O), Q.shape[0], pos0, nh, nkv)
+    return O
+
+
+def to_bf16(x):
+    """round-to-nearest-even f32 -> bf16 bits"""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)

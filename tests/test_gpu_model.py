@@ -1,0 +1,129 @@
+"""GPU parity tests for the whole hot path through the C ABI: session trait, segment-parallel encode, lock-step decode."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cz():
+    import candlezip_amd as m
+    m.lib()
+    return m
+
+
+def _eq(a, b, what):
+    a = np.ascontiguousarray(a, np.float32).view(np.uint32); b = np.ascontiguousarray(b, np.float32).view(np.uint32)
+    n = int(np.sum(a != b))
+    assert n == 0, f"{what}: {n}/{a.size} logits differ"
+
+
+@pytest.fixture(scope="module")
+def tiny_pair(cz, czo):
+    g = cz.Session("smollm", cz.tiny_llama_config(), seed=11, embed_std=0.05, max_streams=8)
+    o = czo.SmolLmSession(czo.tiny_llama_config(), seed=11, embed_std=0.05)
+    yield g, o
+    g.close(); o.close()
+
+
+def test_session_trait_step_and_reprime_bitexact(cz, czo, tiny_pair):
+    g, o = tiny_pair
+    assert g.vocab_size() == o.vocab_size() == 512 and g.max_context_length() == 512
+    rng = np.random.default_rng(0)
+    toks = rng.integers(0, 512, 90).astype(np.uint32)
+    _eq(g.reprime_with_history_and_get_last_logits_tensor(toks[:1]), o.reprime_logits(toks[:1]), "reprime(1)")
+    for i, t in enumerate(toks[1:70]):
+        _eq(g.step_logits_tensor(t), o.step_logits(t), f"step {i}")
+        assert g.index_pos() == o.index_pos() == i + 2
+    _eq(g.reprime_with_history_and_get_last_logits_tensor(toks[10:87]), o.reprime_logits(toks[10:87]), "reprime(77)")
+    assert g.index_pos() == 77
+    _eq(g.step_logits_tensor(toks[87]), o.step_logits(toks[87]), "step after reprime")
+
+
+def test_error_paths_mirror_reference(cz, tiny_pair):
+    g, _ = tiny_pair
+    with pytest.raises(cz.CandlezipError, match="empty history"):
+        g.reprime_with_history_and_get_last_logits_tensor(np.zeros(0, np.uint32))
+    with pytest.raises(cz.CandlezipError, match="vocab"):
+        g.step_logits_tensor(512)
+    with pytest.raises(cz.CandlezipError):
+        cz.Session("smollm", cz.LlamaConfig(512, 100, 2, 2, 1, 256, 2048, 1e5, 1e-5))      # head_dim != 64
+
+
+def test_encode_pairs_and_payload_identical_to_oracle(cz, czo, tiny_pair):
+    g, o = tiny_pair
+    rng = np.random.default_rng(1)
+    ids = np.concatenate([[0], rng.integers(0, 512, 1300)]).astype(np.uint32)      # crosses two re-prime boundaries
+    payload, clo, chi, zw = o.encode_tokens(ids)
+    lo, hi = g.encode_tokens(ids)
+    assert np.array_equal(lo, clo) and np.array_equal(hi, chi)
+    pay, zw2 = cz.ac_encode_pairs(lo, hi)
+    assert pay == payload and zw2 == zw == 0                                           # bitstream-identical to the CPU path
+    out = g.decode_tokens(payload, 1300)
+    assert np.array_equal(out, ids)
+
+
+def test_context_1024_and_small_intervals(cz, czo, tiny_pair):
+    g, o = tiny_pair
+    rng = np.random.default_rng(2)
+    ids = np.concatenate([[0], rng.integers(0, 512, 1100)]).astype(np.uint32)
+    for ctx, R in ((1024, 1024), (512, 256), (512, 100)):
+        p, clo, chi, _ = o.encode_tokens(ids, context=ctx, reprime_interval=R)
+        lo, hi = g.encode_tokens(ids, context=ctx, reprime_interval=R)
+        assert np.array_equal(lo, clo) and np.array_equal(hi, chi), (ctx, R)
+        assert np.array_equal(g.decode_tokens(p, 1100, context_window=ctx, reprime_interval=R), ids), (ctx, R)
+
+
+def test_batched_ragged_streams_roundtrip(cz, czo, tiny_pair):
+    g, o = tiny_pair
+    rng = np.random.default_rng(3)
+    lens = [1, 2, 50, 513, 700, 1025]                      # incl. BOS-only and exactly-at-boundary streams
+    streams = [np.concatenate([[0], rng.integers(0, 512, n - 1)]).astype(np.uint32) for n in lens]
+    pairs = g.encode_tokens_batch(streams)
+    payloads = []
+    for s, (lo, hi) in zip(streams, pairs):
+        ref_p, clo, chi, _ = o.encode_tokens(s)
+        assert np.array_equal(lo, clo) and np.array_equal(hi, chi)
+        p, _ = cz.ac_encode_pairs(lo, hi)
+        assert p == ref_p
+        payloads.append(p)
+    outs = g.decode_tokens_batch(payloads, [n - 1 for n in lens])
+    for s, out in zip(streams, outs):
+        assert np.array_equal(out, s)
+
+
+def test_zero_width_hazard_is_reproduced_and_counted(cz, czo):
+    g = cz.Session("smollm", cz.tiny_llama_config(), seed=5, embed_std=1.5, max_streams=2)
+    o = czo.SmolLmSession(czo.tiny_llama_config(), seed=5, embed_std=1.5)
+    rng = np.random.default_rng(4)
+    ids = np.concatenate([[0], rng.integers(0, 512, 200)]).astype(np.uint32)
+    payload, clo, chi, zw = o.encode_tokens(ids)
+    lo, hi = g.encode_tokens(ids)
+    assert np.array_equal(lo, clo) and np.array_equal(hi, chi)
+    pay, zw2 = cz.ac_encode_pairs(lo, hi)
+    assert pay == payload and zw2 == zw > 0
+    # decoding the undecodable stream must go wrong in exactly the way the reference decoder does
+    assert np.array_equal(g.decode_tokens(payload, 200), o.decode_tokens(payload, 200))
+    g.close(); o.close()
+
+
+def test_smollm2_135m_shape_bitexact(cz, czo):
+    """the BASELINE model shape (SmolLM2-135M: d 576, 30 layers, 9/3 heads, ffn 1536, vocab 49152), synthetic weights"""
+    g = cz.Session("smollm", cz.smollm2_135m_config(), seed=0x5EED, embed_std=0.02, max_streams=4)
+    o = czo.SmolLmSession(czo.smollm2_135m_config(), seed=0x5EED, embed_std=0.02)
+    rng = np.random.default_rng(6)
+    toks = rng.integers(0, 49152, 200).astype(np.uint32)
+    _eq(g.reprime_with_history_and_get_last_logits_tensor(toks[:1]), o.reprime_logits(toks[:1]), "bos step")
+    for i, t in enumerate(toks[1:6]):
+        _eq(g.step_logits_tensor(t), o.step_logits(t), f"step {i}")
+    _eq(g.reprime_with_history_and_get_last_logits_tensor(toks[:150]), o.reprime_logits(toks[:150]), "reprime(150)")
+    _eq(g.step_logits_tensor(toks[150]), o.step_logits(toks[150]), "step@150")
+    ids = np.concatenate([[0], toks[:60]]).astype(np.uint32)
+    payload, clo, chi, zw = o.encode_tokens(ids)
+    lo, hi = g.encode_tokens(ids)
+    assert np.array_equal(lo, clo) and np.array_equal(hi, chi)
+    pay, _ = cz.ac_encode_pairs(lo, hi)
+    assert pay == payload
+    outs = g.decode_tokens_batch([payload, payload[:]], [60, 60])
+    assert np.array_equal(outs[0], ids) and np.array_equal(outs[1], ids)
+    g.close(); o.close()
