@@ -52,10 +52,30 @@ class Decoder(C.Structure):
 _lib = None
 
 
+def _limit_threads():
+    """GPU boxes expose every host core but meter the job to a CPU share: 256 spinning OpenMP threads on a 16-core
+    quota stall for minutes.  Cap the team and make idle threads sleep (must happen before libgomp starts)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:  # cgroup v2 quota
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(n, 16))))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    os.environ.setdefault("OMP_PROC_BIND", "false")
+
+
 def lib():
     global _lib
     if _lib is not None:
         return _lib
+    _limit_threads()
     build()
     L = C.CDLL(_SO)
     vp, sz, u32, u64, f32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_float
