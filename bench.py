@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py — candlezip hot path on MI355X: tokens/sec of the enwik8-style self-test (compress + decompress).
+
+One "step" = one self-test pass (segment-parallel encode -> arithmetic coding -> lock-step decode -> exact round-trip
+check) of this rank's batch of synthetic streams, with token ids and weights resident in HBM-side buffers owned by the
+library.  Workload = BASELINE.json configs[2] ("enwik8 64 KiB samples --backend smollm, chunk-sharded"), SmolLM2-135M
+shape, context 512 / reprime 512: per GPU `--streams` streams of `--tokens` tokens (a 64 KiB enwik8 sample is ~17.4k
+SmolLM2 tokens).  No checkpoint / tokenizer / enwik8 exists offline, so weights are seeded synthetic bf16 tensors and ids
+are uniform random: throughput and roofline are meaningful, bits/byte is not (reported as null).
+
+Contract line (rank 0): metric/value/unit/n_gpus/steps/warmup/ms_per_step/... + "roofline" (dominant kernel family,
+HIP-event timed on the library's stream inside the timed region) + "cpu_baseline" (oracle, reference schedule, bounded
+sample, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak BW (spec)
+
+
+def make_streams(rank, n_streams, n_tokens, vocab):
+    rng = np.random.default_rng(1000 + rank)
+    return [np.concatenate([[0], rng.integers(0, vocab, n_tokens)]).astype(np.uint32) for _ in range(n_streams)]
+
+
+def self_test_step(cz, sess, streams, context, reprime):
+    """compress + decompress of every stream; returns (tokens, payload_bytes, t_encode, t_decode)"""
+    t0 = time.perf_counter()
+    pairs = sess.encode_tokens_batch(streams, context, reprime)
+    payloads = []
+    for lo, hi in pairs:
+        p, zw = cz.ac_encode_pairs(lo, hi)
+        payloads.append(p)
+    t1 = time.perf_counter()
+    outs = sess.decode_tokens_batch(payloads, [s.size - 1 for s in streams], context, reprime, 0)
+    t2 = time.perf_counter()
+    for s, o in zip(streams, outs):
+        if not np.array_equal(s, o):
+            raise RuntimeError("self-test round trip mismatch")
+    return sum(s.size - 1 for s in streams), sum(len(p) for p in payloads), t1 - t0, t2 - t1
+
+
+def cpu_baseline(sample_tokens, context, reprime):
+    """the oracle (CPU restatement of the reference path) in the REFERENCE's schedule: one M=1 forward per token, a
+    511-token batched re-prime every `reprime` tokens, host softmax->CDF->coder per token.  Bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import czo
+    o = czo.SmolLmSession(czo.smollm2_135m_config(), seed=0x5EED, embed_std=0.02)
+    rng = np.random.default_rng(7)
+    ids = np.concatenate([[0], rng.integers(0, 49152, sample_tokens)]).astype(np.uint32)
+    t0 = time.perf_counter()
+    payload, clo, chi, zw = o.encode_tokens(ids, context, reprime)
+    t1 = time.perf_counter()
+    out = o.decode_tokens(payload, sample_tokens, context, reprime, 0)
+    t2 = time.perf_counter()
+    assert np.array_equal(out, ids)
+    cores = czo.lib().czo_num_threads()
+    o.close()
+    return {"value": round(sample_tokens / (t2 - t0), 2), "unit": "tokens/s", "cores": int(cores), "kind": "port",
+            "sample": f"self-test (compress {t1 - t0:.1f}s + decompress {t2 - t1:.1f}s) of one {sample_tokens}-token stream, SmolLM2-135M shape, "
+                      f"ctx {context}/reprime {reprime}, f32, OpenMP oracle",
+            "compress_tokens_per_s": round(sample_tokens / (t1 - t0), 2), "decompress_tokens_per_s": round(sample_tokens / (t2 - t1), 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=48, help="streams (64 KiB chunks) per GPU")
+    ap.add_argument("--tokens", type=int, default=17408, help="tokens per stream (~ one 64 KiB enwik8 sample)")
+    ap.add_argument("--context", type=int, default=512)
+    ap.add_argument("--reprime-interval", type=int, default=512)
+    ap.add_argument("--cpu-sample", type=int, default=640, help="tokens of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check only)")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    import candlezip_amd as cz
+    cfg = cz.tiny_llama_config() if args.tiny else cz.smollm2_135m_config()
+    sess = cz.Session("smollm", cfg, seed=0x5EED, embed_std=0.02, device=local, max_streams=min(64, args.streams))
+    streams = make_streams(rank, args.streams, args.tokens, cfg.vocab)   # files shard across ranks: no data-path collective
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warmup (also finds the dominant kernel family with every family timed)
+    sess.profile_enable(True)
+    for _ in range(max(args.warmup, 1)):
+        self_test_step(cz, sess, streams, args.context, args.reprime_interval)
+    prof_all = sess.profile_read()
+    dominant = max(prof_all, key=lambda k: prof_all[k]["total_ms"]) if prof_all else "gemm_bf16w_f32_mfma"
+    sess.profile_enable(True, only=[dominant])
+
+    barrier()
+    t0 = time.perf_counter()
+    tok = byt = 0; te = td = 0.0
+    for _ in range(args.steps):
+        n, b, e, d = self_test_step(cz, sess, streams, args.context, args.reprime_interval)
+        tok += n; byt += b; te += e; td += d
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = sess.profile_read()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([tok], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total_tok = float(c.item())
+    else:
+        total_tok = float(tok)
+
+    if rank == 0:
+        st = prof.get(dominant, {"launches": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        if dominant.startswith("gemm_bf16w") or dominant.startswith("attention"):
+            achieved = st["flops"] / (st["total_ms"] * 1e-3) / 1e12 if st["total_ms"] else 0.0
+            roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)}
+        else:
+            achieved = st["bytes"] / (st["total_ms"] * 1e-3) / 1e9 if st["total_ms"] else 0.0
+            roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5)}
+        roof.update({"traffic": None, "kernel": dominant, "launches": st["launches"],
+                     "avg_launch_us": round(1e3 * st["total_ms"] / max(st["launches"], 1), 3),
+                     "families_ms_per_step_warmup": {k: round(v["total_ms"] / max(args.warmup, 1), 2) for k, v in prof_all.items()}})
+        line = {
+            "metric": "tokens/sec, enwik8 self-test (compress+decompress), smollm",
+            "value": round(total_tok / elapsed, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"enwik8 64 KiB samples, chunk-sharded: {args.streams} streams x {args.tokens} tokens per GPU, "
+                                   f"SmolLM2-135M shape ({'tiny test model' if args.tiny else 'd576 L30 9q/3kv ffn1536 V49152'}), "
+                                   f"context {args.context}, reprime_interval {args.reprime_interval}, seeded synthetic weights",
+                       "streams_per_gpu": args.streams, "tokens_per_stream": args.tokens, "parallelism": f"files x{world} (no data-path collective)"},
+            "bits_per_byte": None,
+            "bits_per_token_synthetic": round(8.0 * byt / max(tok, 1), 3),
+            "compress_tokens_per_s_rank0": round(tok / te, 1) if te else None,
+            "decompress_tokens_per_s_rank0": round(tok / td, 1) if td else None,
+            "roofline": roof,
+        }
+        if world == 1 and args.cpu_sample > 0 and not args.tiny:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.context, args.reprime_interval)
+        print(json.dumps(line), flush=True)
+    sess.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -112,8 +112,9 @@ def lib():
         "cz_debug_scalar": (C.c_int, [C.c_int, vp, vp, vp, C.c_int]), "cz_debug_f64": (C.c_int, [C.c_int, vp, vp, vp, C.c_int]),
         "cz_debug_gemm": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
         "cz_debug_rmsnorm": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_float]),
-        "cz_debug_cdf_pairs": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
-        "cz_debug_decode_symbols": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, sz, vp]),
+        "cz_debug_cdf_pairs": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+        "cz_debug_decode_symbols": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, sz, vp, C.c_int]),
+        "cz_debug_get": (C.c_long, [vp, C.c_char_p]),
         "cz_debug_attention": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     }
     for name, (res, args) in sig.items():
@@ -221,8 +222,20 @@ class Session:
         return self.decode_tokens_batch([payload], [token_count], context_window, reprime_interval, bos)[0]
 
     # ---- measurement
-    def profile_enable(self, on=True):
-        _check(lib().cz_profile_enable(self.h, 1 if on else 0))
+    KINDS = ["gemm_bf16w_f32_mfma", "gemm_skinny_f32_mfma", "attention_f32_mfma", "rmsnorm", "rope", "swiglu", "embed", "cdf_pairs",
+             "decode_symbol", "rwkv7_step"]
+
+    def profile_enable(self, on=True, only=None):
+        """HIP-event timing per kernel family on the library's stream; `only` = list of family names to time"""
+        v = 0
+        if on:
+            v = 1
+            if only:
+                mask = 0
+                for k in only:
+                    mask |= 1 << self.KINDS.index(k)
+                v = 1 | (mask << 1)
+        _check(lib().cz_profile_enable(self.h, v))
 
     def profile_read(self):
         arr = (KernelStat * 32)()
@@ -237,9 +250,8 @@ class Session:
     def debug_set(self, key, value):
         _check(lib().cz_debug_set(self.h, key.encode(), int(value)))
 
-    def param_count(self):
-        c = None
-        return c
+    def debug_get(self, key):
+        return int(lib().cz_debug_get(self.h, key.encode()))
 
 
 # ---- host-side coder / container (reference: ArithmeticEncoder, write/read_header_v2, blake3 helpers)

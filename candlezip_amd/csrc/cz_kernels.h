@@ -33,8 +33,12 @@ size_t cz_attention_smem_bytes(int max_nk);
 hipError_t cz_attention_prepare(int max_nk);
 
 // logits -> coder interval of `sym` (encode) ; mode 0 = smollm (softmax_pdf), 1 = rwkv7 (floor + 256 literals)
+// (exact-parallel kernel when supported, else the serial walk; fallback_count (optional, device) counts rows that fell back)
 hipError_t cz_launch_cdf_pairs(hipStream_t st, const float* logits, int ld, const uint32_t* sym, uint32_t* c_lo, uint32_t* c_hi,
-                               int rows, int vocab, int mode);
+                               int rows, int vocab, int mode, unsigned* fallback_count);
+hipError_t cz_launch_cdf_pairs_serial(hipStream_t st, const float* logits, int ld, const uint32_t* sym, uint32_t* c_lo, uint32_t* c_hi,
+                                      int rows, int vocab, int mode);
+bool cz_cdf_par_supported(int vocab, int mode);
 // device-resident arithmetic decoder state, one per stream (src/main.rs:406-417)
 struct cz_dec_state {
     unsigned long long low, high, code;
@@ -47,4 +51,6 @@ struct cz_dec_state {
 };
 hipError_t cz_launch_dec_init(hipStream_t st, cz_dec_state* st_arr, int nstreams);
 hipError_t cz_launch_decode_symbol(hipStream_t st, const float* logits, int ld, cz_dec_state* st_arr, uint32_t* sym_out, int nstreams,
-                                   int vocab, int mode, unsigned long long i);
+                                   int vocab, int mode, unsigned long long i, unsigned* fallback_count);
+hipError_t cz_launch_decode_symbol_serial(hipStream_t st, const float* logits, int ld, cz_dec_state* st_arr, uint32_t* sym_out, int nstreams,
+                                          int vocab, int mode, unsigned long long i);

@@ -40,7 +40,8 @@ struct cz_session {
     // packed-row work buffers
     DevBuf tok, x, xn, qkv, gu, h, seqd, roped, rowidx, sym, clo, chi, xl, logits, payload, outids, decst;
     size_t max_batch_rows = 98304, logit_batch_rows = 8192;
-    int force_big_gemm = 0;
+    int force_big_gemm = 0, serial_cdf = 0;
+    unsigned* fallback_dev = nullptr;   // rows the exact-parallel CDF kernel handed to the serial walk
     // lock-step streams
     int max_streams = 64;
     size_t ctx_cap = 0, kv_layer_stride = 0, kv_stream_stride = 0;
@@ -50,7 +51,7 @@ struct cz_session {
     float* step_logits = nullptr; uint32_t* step_sym = nullptr;
     size_t index_pos = 0;              // SmolLmSession::index_pos (src/models.rs:65)
     // profiling
-    bool prof_on = false;
+    bool prof_on = false, prof_cur = false; unsigned prof_mask = 0xFFFFFFFFu;
     ProfAcc acc[PK_COUNT];
     std::vector<ProfEvt> evts; std::vector<hipEvent_t> evt_free; ProfEvt evt_open{};
     void prof_begin(int kind);

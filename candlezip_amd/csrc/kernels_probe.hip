@@ -107,15 +107,23 @@ fail:
 }
 
 // logits [rows][V] -> (c_lo, c_hi) of sym[rows]
-extern "C" cz_status cz_debug_cdf_pairs(const float* logits, const uint32_t* sym, uint32_t* c_lo, uint32_t* c_hi, int rows, int V, int mode) {
+extern "C" cz_status cz_debug_cdf_pairs(const float* logits, const uint32_t* sym, uint32_t* c_lo, uint32_t* c_hi, int rows, int V, int mode, int serial,
+                                        unsigned* fallbacks) {
     DevMem m;
     float* dl = (float*)m.alloc((size_t)rows * V * 4);
     uint32_t *ds = (uint32_t*)m.alloc(rows * 4), *dlo = (uint32_t*)m.alloc(rows * 4), *dhi = (uint32_t*)m.alloc(rows * 4);
     if (!dl || !ds || !dlo || !dhi) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
     PCHK(hipMemcpy(dl, logits, (size_t)rows * V * 4, hipMemcpyHostToDevice));
     PCHK(hipMemcpy(ds, sym, rows * 4, hipMemcpyHostToDevice));
-    PCHK(cz_launch_cdf_pairs(0, dl, V, ds, dlo, dhi, rows, V, mode));
-    PCHK(hipDeviceSynchronize());
+    {
+        unsigned* dfb = (unsigned*)m.alloc(64);
+        if (!dfb) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
+        PCHK(hipMemset(dfb, 0, 64));
+        if (serial) PCHK(cz_launch_cdf_pairs_serial(0, dl, V, ds, dlo, dhi, rows, V, mode));
+        else PCHK(cz_launch_cdf_pairs(0, dl, V, ds, dlo, dhi, rows, V, mode, dfb));
+        PCHK(hipDeviceSynchronize());
+        if (fallbacks) PCHK(hipMemcpy(fallbacks, dfb, 4, hipMemcpyDeviceToHost));
+    }
     PCHK(hipMemcpy(c_lo, dlo, rows * 4, hipMemcpyDeviceToHost));
     PCHK(hipMemcpy(c_hi, dhi, rows * 4, hipMemcpyDeviceToHost));
     return CZ_OK;
@@ -125,7 +133,7 @@ fail:
 
 // decode `steps` symbols of ONE stream from `payload`, using logits[step][V] (teacher-provided), on the device
 extern "C" cz_status cz_debug_decode_symbols(const float* logits, int steps, int V, int mode, const uint8_t* payload, size_t len,
-                                             uint32_t* out_syms) {
+                                             uint32_t* out_syms, int serial) {
     DevMem m;
     float* dl = (float*)m.alloc((size_t)steps * V * 4);
     uint8_t* dp = (uint8_t*)m.alloc(len + 16);
@@ -140,7 +148,10 @@ extern "C" cz_status cz_debug_decode_symbols(const float* logits, int steps, int
     hs.in = dp; hs.in_len = len; hs.out_ids = dout; hs.token_count = (unsigned long long)steps; hs.active = 1;
     PCHK(hipMemcpy(dst, &hs, sizeof hs, hipMemcpyHostToDevice));
     PCHK(cz_launch_dec_init(0, dst, 1));
-    for (int i = 0; i < steps; ++i) PCHK(cz_launch_decode_symbol(0, dl + (size_t)i * V, V, dst, dsym, 1, V, mode, (unsigned long long)i));
+    for (int i = 0; i < steps; ++i) {
+        if (serial) PCHK(cz_launch_decode_symbol_serial(0, dl + (size_t)i * V, V, dst, dsym, 1, V, mode, (unsigned long long)i));
+        else PCHK(cz_launch_decode_symbol(0, dl + (size_t)i * V, V, dst, dsym, 1, V, mode, (unsigned long long)i, nullptr));
+    }
     PCHK(hipDeviceSynchronize());
     PCHK(hipMemcpy(out_syms, dout + 1, (size_t)steps * 4, hipMemcpyDeviceToHost));
     return CZ_OK;

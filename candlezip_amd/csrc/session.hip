@@ -63,7 +63,8 @@ void DevBuf::release() { if (p) { hipError_t e = hipFree(p); (void)e; } p = null
 
 // ------------------------------------------------------------------ profiling (HIP events on the session stream)
 void cz_session::prof_begin(int kind) {
-    if (!prof_on) return;
+    prof_cur = prof_on && ((prof_mask >> kind) & 1u);
+    if (!prof_cur) return;
     ProfEvt ev; ev.kind = kind; ev.flops = 0; ev.bytes = 0;
     if (!evt_free.empty()) { ev.e0 = evt_free.back(); evt_free.pop_back(); ev.e1 = evt_free.back(); evt_free.pop_back(); }
     else { hipEventCreate(&ev.e0); hipEventCreate(&ev.e1); }
@@ -71,7 +72,7 @@ void cz_session::prof_begin(int kind) {
     evt_open = ev;
 }
 void cz_session::prof_end(double flops, double bytes) {
-    if (!prof_on) return;
+    if (!prof_cur) return;
     hipEventRecord(evt_open.e1, stream);
     evt_open.flops = flops; evt_open.bytes = bytes;
     evts.push_back(evt_open);
@@ -410,8 +411,10 @@ static cz_status encode_llama(cz_session* s, size_t n_streams, const uint32_t* c
             const int nr = (int)std::min(LB, Lr - r0);
             CZCHK(llama_head(s, (const int*)s->rowidx.p + r0, nr, (float*)s->logits.p));
             s->prof_begin(PK_CDF);
-            HIPCHK(cz_launch_cdf_pairs(s->stream, (const float*)s->logits.p, c.vocab, (const uint32_t*)s->sym.p + r0, (uint32_t*)s->clo.p + r0,
-                                       (uint32_t*)s->chi.p + r0, nr, c.vocab, 0));
+            if (s->serial_cdf) HIPCHK(cz_launch_cdf_pairs_serial(s->stream, (const float*)s->logits.p, c.vocab, (const uint32_t*)s->sym.p + r0,
+                                                                  (uint32_t*)s->clo.p + r0, (uint32_t*)s->chi.p + r0, nr, c.vocab, 0));
+            else HIPCHK(cz_launch_cdf_pairs(s->stream, (const float*)s->logits.p, c.vocab, (const uint32_t*)s->sym.p + r0, (uint32_t*)s->clo.p + r0,
+                                            (uint32_t*)s->chi.p + r0, nr, c.vocab, 0, s->fallback_dev));
             s->prof_end(0, (double)nr * c.vocab * 4);
         }
         std::vector<uint32_t> lo(Lr), hi(Lr);
@@ -466,7 +469,8 @@ static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* 
             index_pos = hl;
         }
         s->prof_begin(PK_DECODE);
-        HIPCHK(cz_launch_decode_symbol(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, (unsigned long long)i));
+        if (s->serial_cdf) HIPCHK(cz_launch_decode_symbol_serial(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, (unsigned long long)i));
+        else HIPCHK(cz_launch_decode_symbol(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, (unsigned long long)i, s->fallback_dev));
         s->prof_end(0, (double)B * c.vocab * 4);
         if (i + 1 < max_tc) {
             // the reference also steps after the last symbol (:2627); its logits are never used, so it is skipped here
@@ -499,6 +503,7 @@ extern "C" cz_status cz_session_open(const cz_model_desc* desc, int device_ordin
     if (s->max_streams > 64) { delete s; cz_set_error("max_streams > 64 is not supported"); return CZ_ERR_ARG; }
     hipError_t e = hipStreamCreate(&s->stream);
     if (e != hipSuccess) { delete s; cz_set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return CZ_ERR_HIP; }
+    if (hipMalloc((void**)&s->fallback_dev, 64) != hipSuccess || hipMemset(s->fallback_dev, 0, 64) != hipSuccess) { delete s; cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
     cz_status rc = CZ_OK;
     if (desc->backend == CZ_BACKEND_SMOLLM) rc = build_llama(s, desc);
     else if (desc->backend == CZ_BACKEND_RWKV7) rc = cz_rwkv7_build(s, desc);
@@ -517,7 +522,7 @@ extern "C" void cz_session_close(cz_session* s) {
     DevBuf* bufs[] = {&s->tok, &s->x, &s->xn, &s->qkv, &s->gu, &s->h, &s->seqd, &s->roped, &s->rowidx, &s->sym, &s->clo, &s->chi, &s->xl,
                       &s->logits, &s->payload, &s->outids, &s->decst};
     for (auto b : bufs) b->release();
-    void* ptrs[] = {s->llama.blob, s->llama.rope_cos, s->llama.rope_sin, s->kvcache, s->pos_dev, s->step_seqd, s->step_roped, s->step_rows,
+    void* ptrs[] = {s->fallback_dev, s->llama.blob, s->llama.rope_cos, s->llama.rope_sin, s->kvcache, s->pos_dev, s->step_seqd, s->step_roped, s->step_rows,
                     s->step_logits, s->step_sym};
     for (auto p : ptrs) if (p) { hipError_t e = hipFree(p); (void)e; }
     cz_rwkv7_destroy(s);
@@ -593,6 +598,7 @@ extern "C" cz_status cz_profile_enable(cz_session* s, int on) {
     s->prof_drain();
     for (int k = 0; k < PK_COUNT; ++k) s->acc[k] = ProfAcc();
     s->prof_on = on != 0;
+    s->prof_mask = on > 1 ? (unsigned)on >> 1 : 0xFFFFFFFFu;      // on = 1: every kind; on = 1 | (mask << 1): selected kinds
     return CZ_OK;
 }
 extern "C" cz_status cz_profile_read(cz_session* s, cz_kernel_stat* out, size_t cap, size_t* n) {
@@ -622,6 +628,19 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     if (!strcmp(key, "force_big_gemm")) s->force_big_gemm = (int)value;
     else if (!strcmp(key, "max_batch_rows")) s->max_batch_rows = (size_t)value;
     else if (!strcmp(key, "logit_batch_rows")) s->logit_batch_rows = (size_t)value;
+    else if (!strcmp(key, "serial_cdf")) s->serial_cdf = (int)value;
     else { cz_set_error("unknown debug key %s", key); return CZ_ERR_ARG; }
     return CZ_OK;
+}
+
+// number of rows the exact-parallel CDF kernel handed to the serial walk since the session was opened
+extern "C" long cz_debug_get(cz_session* s, const char* key) {
+    if (!s || !key) return -1;
+    if (!strcmp(key, "cdf_fallback_rows")) {
+        unsigned v = 0;
+        hipStreamSynchronize(s->stream);
+        if (hipMemcpy(&v, s->fallback_dev, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        return (long)v;
+    }
+    return -1;
 }

@@ -113,24 +113,74 @@ def test_attention_bitexact(cz, czo, M, pos0, nh, nkv):
     _assert_bitexact(O, czo.attention_ref(Q, K, V, pos0, nh, nkv), "attention")
 
 
+def _cdf_pairs(cz, logits, sym, V, mode, serial):
+    rows = logits.shape[0]
+    lo = np.empty(rows, np.uint32); hi = np.empty(rows, np.uint32); fb = np.zeros(1, np.uint32)
+    rc = cz.lib().cz_debug_cdf_pairs(logits.ctypes.data, sym.ctypes.data, lo.ctypes.data, hi.ctypes.data, rows, V, mode, serial, fb.ctypes.data)
+    assert rc == 0, cz.lib().cz_last_error()
+    return lo, hi, int(fb[0])
+
+
+@pytest.mark.parametrize("serial", [1, 0])
 @pytest.mark.parametrize("V,mode,scale", [(512, 0, 1.0), (512, 0, 30.0), (49152, 0, 2.0), (49152, 0, 12.0), (512, 1, 3.0), (65536, 1, 4.0)])
-def test_cdf_pairs_exact(cz, czo, V, mode, scale):
+def test_cdf_pairs_exact(cz, czo, V, mode, scale, serial):
+    """serial = the reference's own walk, one lane per row; serial=0 = the exact-parallel kernel (mode 0) — both must equal the oracle"""
     rng = np.random.default_rng(V + mode)
     rows = 70 if V < 1000 else 9
     logits = (rng.standard_normal((rows, V)) * scale).astype(np.float32)
     nsym = V if mode == 0 else V + 256
     sym = rng.integers(0, nsym, rows).astype(np.uint32)
     sym[0], sym[1] = 0, nsym - 1
-    lo = np.empty(rows, np.uint32); hi = np.empty(rows, np.uint32)
-    rc = cz.lib().cz_debug_cdf_pairs(logits.ctypes.data, sym.ctypes.data, lo.ctypes.data, hi.ctypes.data, rows, V, mode)
-    assert rc == 0, cz.lib().cz_last_error()
+    lo, hi, _ = _cdf_pairs(cz, logits, sym, V, mode, serial)
     for r in range(rows):
         cdf = czo.logits_to_cdf(logits[r], "smollm" if mode == 0 else "rwkv7")
         assert (lo[r], hi[r]) == (cdf[sym[r]], cdf[sym[r] + 1]), (r, sym[r])
 
 
-@pytest.mark.parametrize("V,mode,scale", [(512, 0, 2.0), (512, 1, 2.0), (512, 0, 40.0)])
-def test_device_arithmetic_decoder_matches_oracle(cz, czo, V, mode, scale):
+def _adversarial_rows(V, rng):
+    """rows built to stress the exact-parallel chain: binade crossings everywhere, ties, zeros, one-hot, flat"""
+    rows = []
+    rows.append(np.sort(rng.standard_normal(V) * 25).astype(np.float32))                   # ascending: crossings at almost every step early
+    rows.append(np.sort(rng.standard_normal(V) * 25)[::-1].astype(np.float32).copy())      # descending: max first, then ever smaller terms
+    rows.append((np.round(rng.standard_normal(V) * 20) * np.float32(0.6931472)).astype(np.float32))   # exps ~ powers of two: ties
+    rows.append(np.zeros(V, np.float32))                                                   # flat: p = 1/V exactly representable? no -> rounding each step
+    onehot = np.full(V, -np.inf, np.float32); onehot[V // 3] = 5.0
+    rows.append(onehot)                                                                    # exp(-inf) = 0 everywhere else
+    r = (rng.standard_normal(V) * 3).astype(np.float32); r[: V // 2] -= 120.0               # first half underflows to subnormal/zero exps
+    rows.append(r)
+    r = (rng.standard_normal(V) * 3).astype(np.float32); r[0] = 60.0                        # huge first term: acc >= 1 from the start
+    rows.append(r)
+    r = (rng.standard_normal(V) * 3).astype(np.float32); r[-1] = 60.0                       # huge last term
+    rows.append(r)
+    for s in (0.5, 4.0, 15.0, 40.0):
+        rows.append((rng.standard_normal(V) * s).astype(np.float32))
+    return np.stack(rows)
+
+
+@pytest.mark.parametrize("V", [1, 2, 511, 1000, 1024, 1025, 40000, 49152])
+def test_exact_parallel_cdf_on_adversarial_rows(cz, czo, V):
+    rng = np.random.default_rng(V)
+    logits = _adversarial_rows(V, rng)
+    rows = logits.shape[0]
+    fallbacks = 0
+    for trial in range(3):
+        sym = rng.integers(0, V, rows).astype(np.uint32)
+        if trial == 0:
+            sym[:] = V - 1
+        if trial == 1:
+            sym[:] = 0
+        lo, hi, fb = _cdf_pairs(cz, logits, sym, V, 0, 0)
+        fallbacks += fb
+        for r in range(rows):
+            cdf = czo.logits_to_cdf(logits[r])
+            assert (lo[r], hi[r]) == (cdf[sym[r]], cdf[sym[r] + 1]), (V, trial, r, sym[r])
+    # the uniform/NaN rows legitimately take the serial walk; everything else must have stayed on the parallel path
+    assert fallbacks <= 3 * 2, fallbacks
+
+
+@pytest.mark.parametrize("serial", [1, 0])
+@pytest.mark.parametrize("V,mode,scale", [(512, 0, 2.0), (512, 1, 2.0), (512, 0, 40.0), (3000, 0, 6.0)])
+def test_device_arithmetic_decoder_matches_oracle(cz, czo, V, mode, scale, serial):
     rng = np.random.default_rng(V * 3 + mode)
     steps = 300
     logits = (rng.standard_normal((steps, V)) * scale).astype(np.float32)
@@ -142,7 +192,7 @@ def test_device_arithmetic_decoder_matches_oracle(cz, czo, V, mode, scale):
     payload = e.finish()
     buf = np.frombuffer(payload, np.uint8).copy()
     out = np.zeros(steps, np.uint32)
-    rc = cz.lib().cz_debug_decode_symbols(logits.ctypes.data, steps, V, mode, buf.ctypes.data, len(payload), out.ctypes.data)
+    rc = cz.lib().cz_debug_decode_symbols(logits.ctypes.data, steps, V, mode, buf.ctypes.data, len(payload), out.ctypes.data, serial)
     assert rc == 0, cz.lib().cz_last_error()
     assert out.tolist() == syms
     # a corrupt / truncated payload must decode to exactly what the reference decoder yields (EOF bits read as 1)
@@ -150,5 +200,22 @@ def test_device_arithmetic_decoder_matches_oracle(cz, czo, V, mode, scale):
     d = czo.ArithmeticDecoder(cut)
     ref = [d.decode_symbol_counts(c) for c in cdfs]
     buf2 = np.frombuffer(cut, np.uint8).copy()
-    rc = cz.lib().cz_debug_decode_symbols(logits.ctypes.data, steps, V, mode, buf2.ctypes.data, len(cut), out.ctypes.data)
+    rc = cz.lib().cz_debug_decode_symbols(logits.ctypes.data, steps, V, mode, buf2.ctypes.data, len(cut), out.ctypes.data, serial)
     assert rc == 0 and out.tolist() == ref
+
+
+def test_decoder_on_49152_vocab_parallel_equals_serial(cz, czo):
+    rng = np.random.default_rng(99)
+    V, steps = 49152, 40
+    logits = (rng.standard_normal((steps, V)) * 5).astype(np.float32)
+    cdfs = [czo.logits_to_cdf(l) for l in logits]
+    syms = [int(rng.choice(np.nonzero(np.diff(c.astype(np.int64)) > 0)[0])) for c in cdfs]
+    e = czo.ArithmeticEncoder()
+    for c, s in zip(cdfs, syms):
+        e.encode_counts(int(c[s]), int(c[s + 1]))
+    payload = e.finish()
+    buf = np.frombuffer(payload, np.uint8).copy()
+    for serial in (0, 1):
+        out = np.zeros(steps, np.uint32)
+        rc = cz.lib().cz_debug_decode_symbols(logits.ctypes.data, steps, V, 0, buf.ctypes.data, len(payload), out.ctypes.data, serial)
+        assert rc == 0 and out.tolist() == syms, serial
