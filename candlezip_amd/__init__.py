@@ -223,7 +223,7 @@ class Session:
 
     # ---- measurement
     KINDS = ["gemm_bf16w_f32_mfma", "gemm_skinny_f32_mfma", "attention_f32_mfma", "rmsnorm", "rope", "swiglu", "embed", "cdf_pairs",
-             "decode_symbol", "rwkv7_step"]
+             "decode_symbol", "rwkv7_step", "dec_gemm_f32_mfma", "dec_attention", "dec_rmsnorm"]
 
     def profile_enable(self, on=True, only=None):
         """HIP-event timing per kernel family on the library's stream; `only` = list of family names to time"""

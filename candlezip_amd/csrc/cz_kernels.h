@@ -51,6 +51,22 @@ struct cz_dec_state {
 };
 hipError_t cz_launch_dec_init(hipStream_t st, cz_dec_state* st_arr, int nstreams);
 hipError_t cz_launch_decode_symbol(hipStream_t st, const float* logits, int ld, cz_dec_state* st_arr, uint32_t* sym_out, int nstreams,
-                                   int vocab, int mode, unsigned long long i, unsigned* fallback_count);
+                                   int vocab, int mode, unsigned long long i, unsigned* fallback_count, const unsigned long long* step_dev);
+hipError_t cz_cdf_par_prepare(int vocab);
 hipError_t cz_launch_decode_symbol_serial(hipStream_t st, const float* logits, int ld, cz_dec_state* st_arr, uint32_t* sym_out, int nstreams,
-                                          int vocab, int mode, unsigned long long i);
+                                          int vocab, int mode, unsigned long long i, const unsigned long long* step_dev);
+
+// ---- lock-step decode path (kernels_decode.hip); "kq" = k-interleaved layout, see the file header
+hipError_t cz_launch_dec_pack(hipStream_t st, const uint16_t* W, uint16_t* Wd, size_t N, int K);
+hipError_t cz_launch_dec_rmsnorm(hipStream_t st, const float* X, int ldx, const uint16_t* w, float* Y, int ldy, int M, int d, float eps);
+// normw != nullptr: A is the residual stream in natural layout and RMSNorm(normw, eps) is applied on the fly
+hipError_t cz_launch_dec_gemm_plain(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* C, int ldc, const float* R, int M, int N, int K,
+                                    const uint16_t* normw, float eps);
+hipError_t cz_launch_dec_gemm_qkv(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* Q, int ldq, int M, int K, int n_heads, int n_kv,
+                                  const cz_rope_desc* descs, size_t kv_off, const int* pos_dev, const float* cs, const float* sn,
+                                  const uint16_t* normw, float eps);
+hipError_t cz_launch_dec_gemm_swiglu(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* H, int ldh, int M, int f, int K,
+                                     const uint16_t* normw, float eps);
+hipError_t cz_dec_attn_prepare(int max_nk);
+hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nstreams, int max_nk,
+                              int n_heads, int n_kv, size_t kv_off, const int* pos_dev);

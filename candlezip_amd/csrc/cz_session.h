@@ -13,13 +13,14 @@ struct DevBuf {
     void release();
 };
 
-enum ProfKind { PK_GEMM = 0, PK_GEMM_SKINNY, PK_ATTN, PK_RMSNORM, PK_ROPE, PK_SWIGLU, PK_EMBED, PK_CDF, PK_DECODE, PK_RWKV, PK_COUNT };
+enum ProfKind { PK_GEMM = 0, PK_GEMM_SKINNY, PK_ATTN, PK_RMSNORM, PK_ROPE, PK_SWIGLU, PK_EMBED, PK_CDF, PK_DECODE, PK_RWKV, PK_DEC_GEMM, PK_DEC_ATTN, PK_DEC_NORM, PK_COUNT };
 struct ProfAcc { uint64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
 struct ProfEvt { hipEvent_t e0, e1; int kind; double flops, bytes; };
 
 struct LlamaModel {
     cz_llama_config cfg{};
     uint16_t* blob = nullptr;          // one allocation: E | per-layer tensors | lnf   (bf16)
+    uint16_t* blob_dec = nullptr;      // the same tensors with K in kq order (decode path); same offsets as blob
     uint16_t* E = nullptr;             // [vocab][d]  (tied lm_head)
     struct Layer { uint16_t *ln1, *wqkv, *wo, *ln2, *wgu, *wd; };
     std::vector<Layer> L;
@@ -40,7 +41,8 @@ struct cz_session {
     // packed-row work buffers
     DevBuf tok, x, xn, qkv, gu, h, seqd, roped, rowidx, sym, clo, chi, xl, logits, payload, outids, decst;
     size_t max_batch_rows = 98304, logit_batch_rows = 8192;
-    int force_big_gemm = 0, serial_cdf = 0;
+    int force_big_gemm = 0, serial_cdf = 0, decode_v1 = 0, no_graph = 0;
+    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; int graph_B = 0; unsigned long long graph_gen = 0;
     unsigned* fallback_dev = nullptr;   // rows the exact-parallel CDF kernel handed to the serial walk
     // lock-step streams
     int max_streams = 64;

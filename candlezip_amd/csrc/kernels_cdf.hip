@@ -44,9 +44,11 @@ hipError_t cz_launch_dec_init(hipStream_t s, cz_dec_state* st, int n) {
 }
 
 __global__ void decode_symbol_serial_kernel(const float* __restrict__ logits, int ld, cz_dec_state* __restrict__ st,
-                                            uint32_t* __restrict__ sym_out, int nstreams, int V, int mode, unsigned long long i) {
+                                            uint32_t* __restrict__ sym_out, int nstreams, int V, int mode, unsigned long long i,
+                                            const unsigned long long* __restrict__ step_dev) {
     const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (sidx >= nstreams) return;
+    if (step_dev) i = *step_dev;
     cz_dec_state d = st[sidx];
     if (!d.active || i >= d.token_count) { if (d.active) { d.active = 0; st[sidx] = d; } return; }
     uint32_t s = 0;
@@ -56,8 +58,8 @@ __global__ void decode_symbol_serial_kernel(const float* __restrict__ logits, in
     st[sidx] = d;
 }
 hipError_t cz_launch_decode_symbol_serial(hipStream_t s, const float* logits, int ld, cz_dec_state* st, uint32_t* sym_out, int nstreams,
-                                          int vocab, int mode, unsigned long long i) {
+                                          int vocab, int mode, unsigned long long i, const unsigned long long* step_dev) {
     if (nstreams <= 0) return hipSuccess;
-    hipLaunchKernelGGL(decode_symbol_serial_kernel, dim3((nstreams + 63) / 64), dim3(64), 0, s, logits, ld, st, sym_out, nstreams, vocab, mode, i);
+    hipLaunchKernelGGL(decode_symbol_serial_kernel, dim3((nstreams + 63) / 64), dim3(64), 0, s, logits, ld, st, sym_out, nstreams, vocab, mode, i, step_dev);
     return hipGetLastError();
 }

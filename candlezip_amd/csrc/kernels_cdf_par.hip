@@ -2,14 +2,14 @@
 //
 // softmax_pdf (src/main.rs:784-801) sums exp() left to right in f64 and quantize_pdf_to_cdf (:805-824) floors a
 // left-to-right running sum of the pdf; the payload depends on every rounding of those two 49 152-long chains, so
-// they cannot be reordered.  This kernel evaluates them with one 1024-thread workgroup per row and is bit-identical
+// they cannot be reordered.  This kernel evaluates them with one 512-thread workgroup per row and is bit-identical
 // to the serial walk (kernels_cdf.hip), which the GPU tests check on adversarial rows.
 //
 // Method (executable model: tests/seqsum_model.py; DESIGN.md "Exact parallel CDF"): thread t owns the contiguous chunk
 // [t*L, (t+1)*L).  While acc stays inside one binade [2^b, 2^(b+1)) every add rounds on the grid u = 2^(b-52) and a
 // tie's direction depends only on the parity of acc/u, so the chunk maps acc_in -> acc_in + D[parity(acc_in)].
 // D0, D1 come from running the TRUE f64 chain over the chunk from the reference starts 2^b and 2^b + u.  An ordered
-// resolve (one lane per wave composes 64 transducers, then thread 0 walks the 16 waves) applies the transducers where
+// resolve (one lane per wave composes 64 transducers, then thread 0 walks the 8 waves) applies the transducers where
 // acc_in is verified to sit in binade b and acc_in + D < 2^(b+1); any other chunk ("dirty": binade crossing, start at
 // 0) is evaluated by its true chain from a scratch copy of its terms, kept by every chunk that is not provably clean.
 // Finally every thread re-runs its true chain from its exact acc_in.  If the resolver ever meets a dirty chunk without
@@ -20,6 +20,8 @@
 
 #define T_PAR 1024
 #define LMAX 48
+#define NWAVE (T_PAR / 64)
+#define POOL_SLOTS 60
 #define B_INVALID (-100000)
 #define B_EMPTY 100000
 
@@ -36,18 +38,20 @@ __device__ __forceinline__ uint32_t quantize_u(double acc) {   // src/main.rs:81
 struct par_smem {
     double D0[T_PAR], D1[T_PAR], acc_in[T_PAR];
     int bexp[T_PAR];
-    unsigned char has_copy[T_PAR];
-    double wsum[16], W0[16], W1[16], win[16];
-    int wb[16], wfast[16];
+    unsigned char has_copy[T_PAR];   // 0 = none, 1..POOL = LDS pool slot + 1, 255 = global scratch
+    double pool[POOL_SLOTS][LMAX];   // copies of the terms of chunks that are not provably clean (usually < 30 per row)
+    unsigned pool_next;
+    double wsum[NWAVE], W0[NWAVE], W1[NWAVE], win[NWAVE];
+    int wb[NWAVE], wfast[NWAVE];
     double total;
-    float redf[16];
+    float redf[NWAVE];
     int flag, L, n;
     unsigned found;
     uint32_t value, lo, hi;
     int ok;
 };
 
-__device__ double block_excl_scan(double v, par_smem& sm) {     // approximate (any order): only guesses binades
+__device__ __forceinline__ double block_excl_scan(double v, par_smem& sm) {     // approximate (any order): only guesses binades
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double inc = v;
 #pragma unroll
@@ -64,9 +68,10 @@ __device__ double block_excl_scan(double v, par_smem& sm) {     // approximate (
 // Returns the exact total; with want_acc_in also the exact running sum before this thread's first term.
 // csum = APPROXIMATE sum of this thread's terms (any rounding; it only feeds the binade guesses).
 template <typename XF>
-__device__ double exact_seq_sum(XF xf, double csum, int cnt, int first, par_smem& sm, double* scratch, bool want_acc_in, double* acc_in_out) {
+__device__ __forceinline__ double exact_seq_sum(XF xf, double csum, int cnt, int first, par_smem& sm, double* scratch, bool want_acc_in, double* acc_in_out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double pstart = block_excl_scan(csum, sm);
+    if (tid == 0) sm.pool_next = 0;
+    const double pstart = block_excl_scan(csum, sm);            // (contains barriers: the reset above is visible afterwards)
     const double pend = pstart + csum;
     int b = B_INVALID; double d0 = 0.0, d1 = 0.0;
     bool copy = false;
@@ -87,11 +92,21 @@ __device__ double exact_seq_sum(XF xf, double csum, int cnt, int first, par_smem
             }
         }
     }
-    sm.bexp[tid] = b; sm.D0[tid] = d0; sm.D1[tid] = d1; sm.has_copy[tid] = copy ? 1 : 0;
+    sm.bexp[tid] = b; sm.D0[tid] = d0; sm.D1[tid] = d1;
+    unsigned char where = 0;
     if (copy) {
+        const unsigned slot = atomicAdd(&sm.pool_next, 1u);
+        if (slot < POOL_SLOTS) {
+            where = (unsigned char)(slot + 1);
 #pragma unroll
-        for (int k = 0; k < LMAX; ++k) if (k < cnt) scratch[first + k] = xf(k);
+            for (int k = 0; k < LMAX; ++k) if (k < cnt) sm.pool[slot][k] = xf(k);
+        } else {
+            where = 255;
+#pragma unroll
+            for (int k = 0; k < LMAX; ++k) if (k < cnt) scratch[first + k] = xf(k);
+        }
     }
+    sm.has_copy[tid] = where;
     __threadfence_block();
     __syncthreads();
     if (lane == 0) {                                             // level 1: compose the wave's 64 transducers
@@ -119,7 +134,7 @@ __device__ double exact_seq_sum(XF xf, double csum, int cnt, int first, par_smem
     if (tid == 0) {                                              // level 2: ordered walk
         double acc = 0.0;
         const int L = sm.L, n = sm.n;
-        for (int w = 0; w < 16; ++w) {
+        for (int w = 0; w < NWAVE; ++w) {
             sm.win[w] = acc;
             const int wbv = sm.wb[w];
             if (wbv == B_EMPTY) { sm.wfast[w] = 1; continue; }
@@ -141,9 +156,11 @@ __device__ double exact_seq_sum(XF xf, double csum, int cnt, int first, par_smem
                     if (cand < pow2_f64(bj + 1)) { acc = cand; done = true; }
                 }
                 if (!done) {
-                    if (!sm.has_copy[t]) { sm.flag = 1; continue; }
+                    const int wh = sm.has_copy[t];
+                    if (!wh) { sm.flag = 1; continue; }
                     const int f0 = t * L, c = n - f0 < L ? n - f0 : L;
-                    for (int k = 0; k < c; ++k) acc = acc + scratch[f0 + k];     // the chunk's true chain
+                    if (wh != 255) { const double* src = sm.pool[wh - 1]; for (int k = 0; k < c; ++k) acc = acc + src[k]; }   // the chunk's true chain
+                    else for (int k = 0; k < c; ++k) acc = acc + scratch[f0 + k];           // pool exhausted (rare): global copy
                 }
             }
         }
@@ -175,8 +192,10 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
                                                         const uint32_t* __restrict__ sym, uint32_t* __restrict__ c_lo,
                                                         uint32_t* __restrict__ c_hi, double* __restrict__ scratch_all,
                                                         cz_dec_state* __restrict__ dst, uint32_t* __restrict__ sym_out,
-                                                        unsigned long long step_i, unsigned* __restrict__ fallback_count) {
+                                                        unsigned long long step_i, unsigned* __restrict__ fallback_count,
+                                                        const unsigned long long* __restrict__ step_dev) {
     __shared__ par_smem sm;
+    if (DECODE && step_dev) step_i = *step_dev;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* scratch = scratch_all + (size_t)blockIdx.x * V;
     const int L = (V + T_PAR - 1) / T_PAR;
@@ -203,7 +222,7 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
         __syncthreads();
         m = sm.redf[0];
 #pragma unroll
-        for (int w = 1; w < 16; ++w) m = sm.redf[w] > m ? sm.redf[w] : m;
+        for (int w = 1; w < NWAVE; ++w) m = sm.redf[w] > m ? sm.redf[w] : m;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < LMAX; ++k) if (k < cnt) ef[k] = cz_expf(ef[k] - m);
@@ -313,20 +332,22 @@ hipError_t cz_launch_cdf_pairs(hipStream_t st, const float* logits, int ld, cons
                                int rows, int vocab, int mode, unsigned* fallback_count) {
     if (rows <= 0) return hipSuccess;
     if (!cz_cdf_par_supported(vocab, mode)) return cz_launch_cdf_pairs_serial(st, logits, ld, sym, c_lo, c_hi, rows, vocab, mode);
-    const int grid = rows < 512 ? rows : 512;
-    hipError_t e = ensure_scratch((size_t)512 * vocab * sizeof(double));
+    const int grid = rows < 1024 ? rows : 1024;
+    hipError_t e = ensure_scratch((size_t)1024 * vocab * sizeof(double));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(cdf_par_kernel<0>, dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, c_lo, c_hi, g_scratch, nullptr, nullptr, 0ull,
-                       fallback_count);
+                       fallback_count, nullptr);
     return hipGetLastError();
 }
 hipError_t cz_launch_decode_symbol(hipStream_t st, const float* logits, int ld, cz_dec_state* st_arr, uint32_t* sym_out, int nstreams,
-                                   int vocab, int mode, unsigned long long i, unsigned* fallback_count) {
+                                   int vocab, int mode, unsigned long long i, unsigned* fallback_count, const unsigned long long* step_dev) {
     if (nstreams <= 0) return hipSuccess;
-    if (!cz_cdf_par_supported(vocab, mode)) return cz_launch_decode_symbol_serial(st, logits, ld, st_arr, sym_out, nstreams, vocab, mode, i);
-    hipError_t e = ensure_scratch((size_t)512 * vocab * sizeof(double));
+    if (!cz_cdf_par_supported(vocab, mode)) return cz_launch_decode_symbol_serial(st, logits, ld, st_arr, sym_out, nstreams, vocab, mode, i, step_dev);
+    hipError_t e = ensure_scratch((size_t)1024 * vocab * sizeof(double));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(cdf_par_kernel<1>, dim3(nstreams), dim3(T_PAR), 0, st, logits, ld, nstreams, vocab, nullptr, nullptr, nullptr, g_scratch, st_arr,
-                       sym_out, i, fallback_count);
+                       sym_out, i, fallback_count, step_dev);
     return hipGetLastError();
 }
+// allocate the scratch up front (graph capture forbids hipMalloc inside the captured region)
+hipError_t cz_cdf_par_prepare(int vocab) { return ensure_scratch((size_t)1024 * vocab * sizeof(double)); }

@@ -1,0 +1,371 @@
+// kernels_decode.hip — the lock-step decode step (M = #streams <= 64 rows), latency-oriented.
+//
+// One token per stream per step: every kernel is tiny, so the step is bound by kernel count, load latency and the KV read
+// (46 080 B x ctx per stream, f32), not by MFMA rate.  Numerics are the canonical ones: identical bits to
+// the big-M kernels and to the oracle.
+//
+// Layouts private to this path ("k-interleaved", kq): inside every 64-wide K chunk, element k = 4t + g is stored at
+// position 16g + t.  The A/B operand of v_mfma_f32_16x16x4_f32 step t in lane (i, g) is element k = 4t + g, so with this
+// layout a lane's 16 operands of a chunk are 16 CONSECUTIVE values (4 x 16-B loads for f32 activations, 2 x 16-B for
+// bf16 weights) while the fmaf chain still runs over k ascending.  Weights are re-packed once at load (dec_pack_kernel);
+// activations that feed a GEMM (xn, att, h) are written in kq by their producers.
+//
+// dec_gemm_kernel<EPI>: block = 16 rows x (2 column tiles of 16); one wave per K chunk (rounds of NW waves); chunk
+//   partials meet in LDS and are summed in chunk order.  Epilogues: plain(+residual), RoPE+KV-cache write for the fused
+//   QKV projection (tile pair = columns c and c+32 of one head), SwiGLU for the fused gate|up projection.
+// dec_attn_kernel: one block per (stream, kv head): VALU fmaf chains (lane = key for q.k, lane = d for p.v), K/V rows read
+//   once and shared by the rep query heads of the group.
+#include "cz_kernels.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ __forceinline__ int kq_index(int k) { return (k & ~63) | ((k & 3) << 4) | ((k & 63) >> 2); }
+
+// Wd[n][kq(k)] = W[n][k]
+__global__ void dec_pack_kernel(const uint16_t* __restrict__ W, uint16_t* __restrict__ Wd, size_t N, int K) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < N * (size_t)K; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / K; const int k = (int)(i % K);
+        Wd[n * K + kq_index(k)] = W[i];
+    }
+}
+hipError_t cz_launch_dec_pack(hipStream_t st, const uint16_t* W, uint16_t* Wd, size_t N, int K) {
+    hipLaunchKernelGGL(dec_pack_kernel, dim3(2048), dim3(256), 0, st, W, Wd, N, K);
+    return hipGetLastError();
+}
+
+// RMSNorm for the decode path: same arithmetic as rmsnorm_kernel, output in kq layout (feeds dec_gemm_kernel)
+__global__ __launch_bounds__(256) void dec_rmsnorm_kernel(const float* __restrict__ X, int ldx, const uint16_t* __restrict__ w,
+                                                          float* __restrict__ Y, int ldy, int M, int d, float eps) {
+    __shared__ float part[16][17];
+    __shared__ float mval[16];
+    const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
+    const int m = blockIdx.x * 16 + r;
+    const int nch = d / 64;
+    if (m < M && c < nch) {
+        float p = 0.0f;
+        const f32x4* src = reinterpret_cast<const f32x4*>(X + (size_t)m * ldx + c * 64);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            f32x4 v = src[k];
+            float s0 = v[0] * v[0], s1 = v[1] * v[1], s2 = v[2] * v[2], s3 = v[3] * v[3];
+            p = p + s0; p = p + s1; p = p + s2; p = p + s3;
+        }
+        part[r][c] = p;
+    }
+    __syncthreads();
+    if (m < M && c == 0) {
+        float t = part[r][0];
+        for (int k = 1; k < nch; ++k) t = t + part[r][k];
+        mval[r] = sqrtf(t / (float)d + eps);
+    }
+    __syncthreads();
+    for (int i = tid; i < 16 * d; i += 256) {
+        const int rr = i / d, k = i % d;
+        const int mm = blockIdx.x * 16 + rr;
+        if (mm >= M) break;
+        const float v = X[(size_t)mm * ldx + k];
+        Y[(size_t)mm * ldy + kq_index(k)] = v / mval[rr] * cz_bf16_to_f32(w[k]);
+    }
+}
+hipError_t cz_launch_dec_rmsnorm(hipStream_t st, const float* X, int ldx, const uint16_t* w, float* Y, int ldy, int M, int d, float eps) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(dec_rmsnorm_kernel, dim3((M + 15) / 16), dim3(256), 0, st, X, ldx, w, Y, ldy, M, d, eps);
+    return hipGetLastError();
+}
+
+enum { EPI_PLAIN = 0, EPI_ROPE = 1, EPI_SWIGLU = 2 };
+struct dec_gemm_args {
+    const float* A; int lda;             // kq layout, [M][K]
+    const uint16_t* Wd;                  // kq-packed bf16 [N][K]
+    int M, N, K;
+    float* C; int ldc;                   // EPI_PLAIN: natural layout out (+ residual R, may alias C); EPI_SWIGLU: kq layout out [M][N/2]
+    const float* R;
+    // NORM: A is the residual stream x in NATURAL layout; the block applies RMSNorm (weights normw, bf16) on the fly
+    const uint16_t* normw; float eps;
+    // EPI_ROPE
+    int n_heads, n_kv;
+    const cz_rope_desc* descs; size_t kv_off; const int* pos_dev; const float* cs; const float* sn;
+};
+
+template <int EPI, int NORM>
+__global__ __launch_bounds__(768) void dec_gemm_kernel(dec_gemm_args a) {
+    extern __shared__ __attribute__((aligned(16))) float part[];       // [NW][2][16][17]
+    __shared__ float nsq[16][17];
+    __shared__ float nm[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int m0 = blockIdx.y * 16;
+    // column tiles of this block
+    int n0, n1;
+    if (EPI == EPI_ROPE) {                       // pair (c, c+32) inside one 64-wide head; v heads: two plain tiles of the same head
+        const int head = blockIdx.x >> 1, j = blockIdx.x & 1;
+        n0 = head * 64 + j * 16; n1 = n0 + 32;
+    } else if (EPI == EPI_SWIGLU) {              // gate tile + matching up tile
+        n0 = blockIdx.x * 16; n1 = a.N / 2 + n0;
+    } else {
+        n0 = blockIdx.x * 32; n1 = n0 + 16;
+    }
+    const int K = a.K, nch = K >> 6;
+    const int arow = m0 + li;
+    if (NORM) {
+        // candle rms_norm: m = sqrt(sum(x*x)/d + eps) with the canonical chunk-64 sum; y = x / m * w   (K <= 1024)
+        if (tid < 16 * nch) {
+            const int r = tid / nch, c = tid % nch;
+            float p = 0.0f;
+            if (m0 + r < a.M) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(a.A + (size_t)(m0 + r) * a.lda + c * 64);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const f32x4 v = src[k];
+                    const float s0 = v[0] * v[0], s1 = v[1] * v[1], s2 = v[2] * v[2], s3 = v[3] * v[3];
+                    p = p + s0; p = p + s1; p = p + s2; p = p + s3;
+                }
+            }
+            nsq[r][c] = p;
+        }
+        __syncthreads();
+        if (tid < 16) {
+            float t = nsq[tid][0];
+            for (int k = 1; k < nch; ++k) t = t + nsq[tid][k];
+            nm[tid] = sqrtf(t / (float)K + a.eps);
+        }
+        __syncthreads();
+    }
+    float tot0 = 0.0f, tot1 = 0.0f;              // element (r = tid >> 4, c = tid & 15) of both tiles, owned by threads 0..255
+    for (int c0 = 0; c0 < nch; c0 += NW) {
+        const int c = c0 + wave;
+        if (c < nch) {
+            f32x4 av[4];
+            if (arow >= a.M) { av[0] = av[1] = av[2] = av[3] = f32x4{0, 0, 0, 0}; }
+            else if (NORM) {
+                const float* xr = a.A + (size_t)arow * a.lda + c * 64 + lg;        // natural layout: k = 4t + g
+                const uint16_t* wr = a.normw + c * 64 + lg;
+                const float mv = nm[li];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) av[t >> 2][t & 3] = xr[4 * t] / mv * cz_bf16_to_f32(wr[4 * t]);
+            } else {
+                const f32x4* ap = reinterpret_cast<const f32x4*>(a.A + (size_t)arow * a.lda + c * 64 + lg * 16);
+                av[0] = ap[0]; av[1] = ap[1]; av[2] = ap[2]; av[3] = ap[3];
+            }
+            const uint4* b0p = reinterpret_cast<const uint4*>(a.Wd + (size_t)(n0 + li) * K + c * 64 + lg * 16);
+            const uint4* b1p = reinterpret_cast<const uint4*>(a.Wd + (size_t)(n1 + li) * K + c * 64 + lg * 16);
+            const uint4 b0a = b0p[0], b0b = b0p[1], b1a = b1p[0], b1b = b1p[1];
+            const unsigned w0[8] = {b0a.x, b0a.y, b0a.z, b0a.w, b0b.x, b0b.y, b0b.z, b0b.w};
+            const unsigned w1[8] = {b1a.x, b1a.y, b1a.z, b1a.w, b1b.x, b1b.y, b1b.z, b1b.w};
+            f32x4 acc0 = f32x4{0, 0, 0, 0}, acc1 = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float av_t = av[t >> 2][t & 3];
+                const float bv0 = (t & 1) ? cz_bits_f32(w0[t >> 1] & 0xffff0000u) : cz_bits_f32(w0[t >> 1] << 16);
+                const float bv1 = (t & 1) ? cz_bits_f32(w1[t >> 1] & 0xffff0000u) : cz_bits_f32(w1[t >> 1] << 16);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av_t, bv0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av_t, bv1, acc1, 0, 0, 0);
+            }
+            float* p = part + wave * (2 * 16 * 17);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {       // C/D: col = li, row = 4*lg + r
+                p[(4 * lg + r) * 17 + li] = acc0[r];
+                p[16 * 17 + (4 * lg + r) * 17 + li] = acc1[r];
+            }
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int r = tid >> 4, cc = tid & 15;
+            const int lim = nch - c0 < NW ? nch - c0 : NW;
+            for (int w = 0; w < lim; ++w) {
+                const float p0 = part[w * (2 * 16 * 17) + r * 17 + cc], p1 = part[w * (2 * 16 * 17) + 16 * 17 + r * 17 + cc];
+                if (c0 + w == 0) { tot0 = p0; tot1 = p1; } else { tot0 = tot0 + p0; tot1 = tot1 + p1; }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid >= 256) return;
+    const int r = tid >> 4, cc = tid & 15, row = m0 + r;
+    if (row >= a.M) return;
+    if (EPI == EPI_PLAIN) {
+        float v0 = tot0, v1 = tot1;
+        if (a.R) { v0 = v0 + a.R[(size_t)row * a.ldc + n0 + cc]; v1 = v1 + a.R[(size_t)row * a.ldc + n1 + cc]; }
+        a.C[(size_t)row * a.ldc + n0 + cc] = v0;
+        a.C[(size_t)row * a.ldc + n1 + cc] = v1;
+    } else if (EPI == EPI_SWIGLU) {
+        a.C[(size_t)row * a.ldc + kq_index(n0 + cc)] = cz_siluf(tot0) * tot1;      // silu(gate) * up  (llama.rs MLP)
+    } else {
+        cz_rope_desc d = a.descs[row];           // one row per stream
+        const int pos = a.pos_dev ? *a.pos_dev : d.pos0;
+        const int head = n0 >> 6, i = (n0 & 63) + cc;                             // rotation index i in [0, 32)
+        if (head < a.n_heads + a.n_kv) {
+            const float c_ = a.cs[(size_t)pos * 32 + i], s_ = a.sn[(size_t)pos * 32 + i];
+            const float x1 = tot0, x2 = tot1;
+            const float aa = x1 * c_, bb = x2 * s_, c2 = x1 * s_, dd = x2 * c_;      // candle rope: products rounded separately
+            const float o1 = aa - bb, o2 = c2 + dd;
+            if (head < a.n_heads) {
+                a.C[(size_t)row * a.ldc + head * 64 + i] = o1; a.C[(size_t)row * a.ldc + head * 64 + i + 32] = o2;
+            } else {
+                float* kd = d.k_dst + a.kv_off + (size_t)pos * d.dst_stride + (head - a.n_heads) * 64;
+                kd[i] = o1; kd[i + 32] = o2;
+            }
+        } else {
+            float* vd = d.v_dst + a.kv_off + (size_t)pos * d.dst_stride + (head - a.n_heads - a.n_kv) * 64;
+            vd[i] = tot0; vd[i + 32] = tot1;
+        }
+    }
+}
+
+static int dec_nw(int K) { int nch = K / 64; nch = nch < 12 ? nch : 12; return nch < 4 ? 4 : nch; }   // >= 256 threads: one per element of a tile
+template <int EPI>
+static hipError_t dec_gemm_launch(hipStream_t st, const dec_gemm_args& a, int gx) {
+    const int NW = dec_nw(a.K);
+    const size_t smem = (size_t)NW * 2 * 16 * 17 * sizeof(float);
+    if (a.normw) {
+        if (a.K > 1024) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((dec_gemm_kernel<EPI, 1>), dim3(gx, (a.M + 15) / 16), dim3(64 * NW), smem, st, a);
+    } else hipLaunchKernelGGL((dec_gemm_kernel<EPI, 0>), dim3(gx, (a.M + 15) / 16), dim3(64 * NW), smem, st, a);
+    return hipGetLastError();
+}
+// C[M][N] (natural) = A(kq) . W^T (+ R)
+hipError_t cz_launch_dec_gemm_plain(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* C, int ldc, const float* R, int M, int N, int K,
+                                    const uint16_t* normw, float eps) {
+    if (M <= 0) return hipSuccess;
+    if (N % 32 || K % 64) return hipErrorInvalidValue;
+    dec_gemm_args a{}; a.A = A; a.lda = lda; a.Wd = Wd; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc; a.R = R; a.normw = normw; a.eps = eps;
+    return dec_gemm_launch<EPI_PLAIN>(st, a, N / 32);
+}
+// fused QKV projection + RoPE; q -> Q [M][n_heads*64] natural, k/v -> per-stream cache rows at position *pos_dev
+hipError_t cz_launch_dec_gemm_qkv(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* Q, int ldq, int M, int K, int n_heads, int n_kv,
+                                  const cz_rope_desc* descs, size_t kv_off, const int* pos_dev, const float* cs, const float* sn,
+                                  const uint16_t* normw, float eps) {
+    if (M <= 0) return hipSuccess;
+    if (K % 64) return hipErrorInvalidValue;
+    dec_gemm_args a{}; a.normw = normw; a.eps = eps; a.A = A; a.lda = lda; a.Wd = Wd; a.M = M; a.N = (n_heads + 2 * n_kv) * 64; a.K = K; a.C = Q; a.ldc = ldq;
+    a.n_heads = n_heads; a.n_kv = n_kv; a.descs = descs; a.kv_off = kv_off; a.pos_dev = pos_dev; a.cs = cs; a.sn = sn;
+    return dec_gemm_launch<EPI_ROPE>(st, a, (n_heads + 2 * n_kv) * 2);
+}
+// fused gate|up projection + SwiGLU; H [M][f] in kq layout
+hipError_t cz_launch_dec_gemm_swiglu(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* H, int ldh, int M, int f, int K,
+                                     const uint16_t* normw, float eps) {
+    if (M <= 0) return hipSuccess;
+    if (f % 64 || K % 64) return hipErrorInvalidValue;
+    dec_gemm_args a{}; a.normw = normw; a.eps = eps; a.A = A; a.lda = lda; a.Wd = Wd; a.M = M; a.N = 2 * f; a.K = K; a.C = H; a.ldc = ldh;
+    return dec_gemm_launch<EPI_SWIGLU>(st, a, f / 16);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// decode attention: block = (stream, kv head), 512 threads.  Same arithmetic as attention_kernel.
+#define DA_THREADS 512
+#define DA_MAXREP 4
+__global__ __launch_bounds__(DA_THREADS) void dec_attn_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
+                                                              const cz_seq_desc* __restrict__ descs, int n_heads, int n_kv, int s_stride,
+                                                              size_t kv_off, const int* __restrict__ pos_dev) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    cz_seq_desc sd = descs[blockIdx.x];
+    const int pos = pos_dev ? *pos_dev : sd.pos0;
+    const int nk = pos + 1, nch = (nk + 63) >> 6, nkp = nch * 64;
+    const int kvh = blockIdx.y, rep = n_heads / n_kv;
+    const float* Kb = sd.k + kv_off + kvh * 64;
+    const float* Vb = sd.v + kv_off + kvh * 64;
+    float* qs = smem;                                   // [DA_MAXREP][64]
+    float* S = qs + DA_MAXREP * 64;                     // [rep][s_stride]
+    float* part = S + DA_MAXREP * s_stride;             // [nch][DA_MAXREP][64]
+    float* red = part + 32 * DA_MAXREP * 64;            // [DA_MAXREP][32] + [DA_MAXREP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NWV = DA_THREADS / 64;
+    if (tid < rep * 64) qs[tid] = Q[(size_t)sd.row0 * ldq + (kvh * rep + (tid >> 6)) * 64 + (tid & 63)];
+    __syncthreads();
+    // scores: lane = key
+    for (int c = wave; c < nch; c += NWV) {
+        const int j = c * 64 + lane;
+        float s[DA_MAXREP] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (j < nk) {
+            const f32x4* kr = reinterpret_cast<const f32x4*>(Kb + (size_t)j * sd.kv_stride);
+#pragma unroll
+            for (int q4 = 0; q4 < 16; ++q4) {
+                const f32x4 kv = kr[q4];
+#pragma unroll
+                for (int h = 0; h < DA_MAXREP; ++h)
+                    if (h < rep) {
+                        const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + h * 64 + q4 * 4);
+                        s[h] = cz_fma(qv[0], kv[0], s[h]); s[h] = cz_fma(qv[1], kv[1], s[h]);
+                        s[h] = cz_fma(qv[2], kv[2], s[h]); s[h] = cz_fma(qv[3], kv[3], s[h]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) S[h * s_stride + j] = j < nk ? s[h] * 0.125f : -INFINITY;
+    }
+    __syncthreads();
+    // row max
+    {
+        const int h = tid >> 7, q = tid & 127;          // 128 threads per head (rep <= 4)
+        float m = -INFINITY;
+        if (h < rep) for (int j = q; j < nkp; j += 128) { const float v = S[h * s_stride + j]; m = v > m ? v : m; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const float y = __shfl_xor(m, o); m = y > m ? y : m; }
+        if (lane == 0) red[wave] = m;
+    }
+    __syncthreads();
+    if (tid < rep) { const float a = red[tid * 2], b = red[tid * 2 + 1]; red[16 + tid] = a > b ? a : b; }
+    __syncthreads();
+    for (int h = 0; h < rep; ++h) {
+        const float mx = red[16 + h];
+        for (int j = tid; j < nkp; j += DA_THREADS) S[h * s_stride + j] = cz_expf(S[h * s_stride + j] - mx);
+    }
+    __syncthreads();
+    // canonical sum: (head, chunk) sequential partials, chunks left to right
+    for (int i = tid; i < rep * nch; i += DA_THREADS) {
+        const int h = i / nch, c = i % nch;
+        const float* p = S + h * s_stride + c * 64;
+        float acc = 0.0f;
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k) acc = acc + p[k];
+        part[h * 32 + c] = acc;
+    }
+    __syncthreads();
+    if (tid < rep) {
+        float t = part[tid * 32];
+        for (int c = 1; c < nch; ++c) t = t + part[tid * 32 + c];
+        red[24 + tid] = t;
+    }
+    __syncthreads();
+    for (int h = 0; h < rep; ++h) {
+        const float sm_ = red[24 + h];
+        for (int j = tid; j < nkp; j += DA_THREADS) S[h * s_stride + j] = S[h * s_stride + j] / sm_;
+    }
+    __syncthreads();
+    // P.V: lane = d, chunk partials (fmaf chain over keys ascending), then chunks left to right
+    for (int c = wave; c < nch; c += NWV) {
+        float acc[DA_MAXREP] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int jend = nk - c * 64 < 64 ? nk - c * 64 : 64;
+        const float* vp = Vb + (size_t)(c * 64) * sd.kv_stride + lane;
+        float vreg[64];                                   // the whole 64-key slab of this lane's column: all loads in flight at once
+#pragma unroll
+        for (int j = 0; j < 64; ++j) vreg[j] = j < jend ? vp[(size_t)j * sd.kv_stride] : 0.0f;
+        // keys past nk have p == 0 (exp(-inf)) and v == 0: fma(0, 0, acc) == acc, so the chain below needs no guard
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+#pragma unroll
+            for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) acc[h] = cz_fma(S[h * s_stride + c * 64 + j], vreg[j], acc[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) part[(c * DA_MAXREP + h) * 64 + lane] = acc[h];
+    }
+    __syncthreads();
+    if (tid < rep * 64) {
+        const int h = tid >> 6, dd = tid & 63;
+        float t = part[(0 * DA_MAXREP + h) * 64 + dd];
+        for (int c = 1; c < nch; ++c) t = t + part[(c * DA_MAXREP + h) * 64 + dd];
+        O[(size_t)sd.row0 * ldo + kq_index((kvh * rep + h) * 64 + dd)] = t;      // kq layout: feeds the o-projection
+    }
+}
+static int da_s_stride(int max_nk) { return ((max_nk + 63) / 64) * 64 + 4; }
+static size_t da_smem(int max_nk) { return (size_t)(DA_MAXREP * 64 + DA_MAXREP * da_s_stride(max_nk) + 32 * DA_MAXREP * 64 + 64) * sizeof(float); }
+hipError_t cz_dec_attn_prepare(int max_nk) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk));
+}
+hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nstreams, int max_nk,
+                              int n_heads, int n_kv, size_t kv_off, const int* pos_dev) {
+    if (nstreams <= 0) return hipSuccess;
+    const int rep = n_heads / n_kv;
+    if (rep < 1 || rep > DA_MAXREP || max_nk > 2048) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dec_attn_kernel, dim3(nstreams, n_kv), dim3(DA_THREADS), da_smem(max_nk), st, Q, ldq, O, ldo, descs, n_heads, n_kv,
+                       da_s_stride(max_nk), kv_off, pos_dev);
+    return hipGetLastError();
+}

@@ -149,8 +149,8 @@ extern "C" cz_status cz_debug_decode_symbols(const float* logits, int steps, int
     PCHK(hipMemcpy(dst, &hs, sizeof hs, hipMemcpyHostToDevice));
     PCHK(cz_launch_dec_init(0, dst, 1));
     for (int i = 0; i < steps; ++i) {
-        if (serial) PCHK(cz_launch_decode_symbol_serial(0, dl + (size_t)i * V, V, dst, dsym, 1, V, mode, (unsigned long long)i));
-        else PCHK(cz_launch_decode_symbol(0, dl + (size_t)i * V, V, dst, dsym, 1, V, mode, (unsigned long long)i, nullptr));
+        if (serial) PCHK(cz_launch_decode_symbol_serial(0, dl + (size_t)i * V, V, dst, dsym, 1, V, mode, (unsigned long long)i, nullptr));
+        else PCHK(cz_launch_decode_symbol(0, dl + (size_t)i * V, V, dst, dsym, 1, V, mode, (unsigned long long)i, nullptr, nullptr));
     }
     PCHK(hipDeviceSynchronize());
     PCHK(hipMemcpy(out_syms, dout + 1, (size_t)steps * 4, hipMemcpyDeviceToHost));

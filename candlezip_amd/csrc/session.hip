@@ -35,6 +35,9 @@ __global__ void synth_kernel(uint16_t* dst, size_t numel, uint64_t seed, uint32_
         dst[i] = cz_synth_bf16(seed, tid, i, stdv, mean);
 }
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
+// device-resident counters of the lock-step decode loop: pos_dev[0] = position, (u64*)(pos_dev + 2) = token index i
+__global__ void set_counters_kernel(int* p, int pos, unsigned long long step) { p[0] = pos; *reinterpret_cast<unsigned long long*>(p + 2) = step; }
+__global__ void inc_counters_kernel(int* p) { p[0] += 1; *reinterpret_cast<unsigned long long*>(p + 2) += 1ull; }
 __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 __global__ void init_out_ids_kernel(cz_dec_state* st, int n, uint32_t bos) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,8 +54,10 @@ __global__ void gather_hist_kernel(const cz_dec_state* st, uint32_t* tok, int ns
     tok[i] = st[b].out_ids[idx];
 }
 
+static unsigned long long g_devbuf_gen = 0;       // bumped whenever any work buffer moves: captured graphs hold raw pointers
 cz_status DevBuf::ensure(size_t bytes) {
     if (bytes <= cap) return CZ_OK;
+    ++g_devbuf_gen;
     if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
     size_t want = bytes + bytes / 8 + 256;
     HIPCHK(hipMalloc(&p, want));
@@ -90,7 +95,7 @@ void cz_session::prof_drain() {
     evts.clear();
 }
 static const char* kProfNames[PK_COUNT] = {"gemm_bf16w_f32_mfma", "gemm_skinny_f32_mfma", "attention_f32_mfma", "rmsnorm", "rope",
-                                           "swiglu", "embed", "cdf_pairs", "decode_symbol", "rwkv7_step"};
+                                           "swiglu", "embed", "cdf_pairs", "decode_symbol", "rwkv7_step", "dec_gemm_f32_mfma", "dec_attention", "dec_rmsnorm"};
 
 // ------------------------------------------------------------------ model construction
 static cz_status synth(cz_session* s, uint16_t* dst, const char* name, size_t numel, float stdv, float mean) {
@@ -217,6 +222,17 @@ static cz_status build_llama(cz_session* s, const cz_model_desc* desc) {
     HIPCHK(hipMalloc((void**)&m.rope_sin, hs.size() * 4));
     HIPCHK(hipMemcpy(m.rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(m.rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+    // decode-path copy of the matrices with K in kq order (kernels_decode.hip)
+    HIPCHK(hipMalloc((void**)&m.blob_dec, total * 2));
+    auto dec = [&](const uint16_t* w) { return m.blob_dec + (w - m.blob); };
+    HIPCHK(cz_launch_dec_pack(s->stream, m.E, dec(m.E), V, (int)d));
+    for (size_t l = 0; l < L; ++l) {
+        const LlamaModel::Layer& y = m.L[l];
+        HIPCHK(cz_launch_dec_pack(s->stream, y.wqkv, dec(y.wqkv), d + 2 * kvd, (int)d));
+        HIPCHK(cz_launch_dec_pack(s->stream, y.wo, dec(y.wo), d, (int)d));
+        HIPCHK(cz_launch_dec_pack(s->stream, y.wgu, dec(y.wgu), 2 * f, (int)d));
+        HIPCHK(cz_launch_dec_pack(s->stream, y.wd, dec(y.wd), d, (int)f));
+    }
     HIPCHK(hipStreamSynchronize(s->stream));
     return CZ_OK;
 }
@@ -304,10 +320,42 @@ static cz_status ensure_streams(cz_session* s, int B) {
     }
     return CZ_OK;
 }
+// the lock-step decode step on the dedicated latency-oriented kernels (kernels_decode.hip)
+static cz_status llama_step_fast(cz_session* s, int B, int pos, int max_nk) {
+    const LlamaModel& m = s->llama; const cz_llama_config& c = m.cfg;
+    const int d = c.d_model, f = c.d_ffn;
+    CZCHK(s->x.ensure((size_t)B * d * 4)); CZCHK(s->xn.ensure((size_t)B * d * 4)); CZCHK(s->qkv.ensure((size_t)B * d * 4));
+    CZCHK(s->gu.ensure((size_t)B * d * 4)); CZCHK(s->h.ensure((size_t)B * f * 4));
+    float *x = (float*)s->x.p, *q = (float*)s->qkv.p, *att = (float*)s->gu.p, *h = (float*)s->h.p;
+    hipStream_t st = s->stream;
+    auto dec = [&](const uint16_t* w) { return m.blob_dec + (w - m.blob); };
+    s->prof_begin(PK_EMBED); HIPCHK(cz_launch_embed(st, (const uint32_t*)s->tok.p, m.E, x, B, d)); s->prof_end(0, (double)B * d * 6);
+    const int kvd = c.n_kv_heads * 64, nq = d + 2 * kvd;
+    for (int l = 0; l < c.n_layers; ++l) {
+        const LlamaModel::Layer& y = m.L[l];
+        const size_t kv_off = (size_t)l * s->kv_layer_stride;
+        s->prof_begin(PK_DEC_GEMM);                                                        // RMSNorm(ln1) fused into the A load
+        HIPCHK(cz_launch_dec_gemm_qkv(st, x, d, dec(y.wqkv), q, d, B, d, c.n_heads, c.n_kv_heads, s->step_roped, kv_off, s->pos_dev, m.rope_cos, m.rope_sin,
+                                      y.ln1, c.rms_eps));
+        s->prof_end(2.0 * B * (double)nq * d, (double)nq * d * 2);
+        s->prof_begin(PK_DEC_ATTN);
+        HIPCHK(cz_launch_dec_attn(st, q, d, att, d, s->step_seqd, B, max_nk, c.n_heads, c.n_kv_heads, kv_off, s->pos_dev));
+        s->prof_end(4.0 * 64 * c.n_heads * (double)B * (pos + 1), 2.0 * B * (double)(pos + 1) * kvd * 4);
+        s->prof_begin(PK_DEC_GEMM); HIPCHK(cz_launch_dec_gemm_plain(st, att, d, dec(y.wo), x, d, x, B, d, d, nullptr, 0.0f)); s->prof_end(2.0 * B * (double)d * d, (double)d * d * 2);
+        s->prof_begin(PK_DEC_GEMM); HIPCHK(cz_launch_dec_gemm_swiglu(st, x, d, dec(y.wgu), h, f, B, f, d, y.ln2, c.rms_eps)); s->prof_end(4.0 * B * (double)f * d, (double)f * d * 4);
+        s->prof_begin(PK_DEC_GEMM); HIPCHK(cz_launch_dec_gemm_plain(st, h, f, dec(y.wd), x, d, x, B, d, f, nullptr, 0.0f)); s->prof_end(2.0 * B * (double)d * f, (double)d * f * 2);
+    }
+    s->prof_begin(PK_DEC_GEMM);                                                            // final RMSNorm fused into the lm_head
+    HIPCHK(cz_launch_dec_gemm_plain(st, x, d, dec(m.E), s->step_logits, c.vocab, nullptr, B, c.vocab, d, m.lnf, c.rms_eps));
+    s->prof_end(2.0 * B * (double)c.vocab * d, (double)c.vocab * d * 2 + (double)B * c.vocab * 4);
+    return CZ_OK;
+}
 // one token per stream at position `pos` (tokens in s->tok[0..B)); logits -> s->step_logits [B][V]
 static cz_status llama_step(cz_session* s, int B, int pos) {
     if (pos >= CZ_MAX_CTX || pos >= s->llama.cfg.max_pos) { cz_set_error("position %d exceeds the supported context (%d)", pos, CZ_MAX_CTX); return CZ_ERR_STATE; }
     hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, pos);
+    if (!s->decode_v1 && s->llama.cfg.n_heads / s->llama.cfg.n_kv_heads <= 4) return llama_step_fast(s, B, pos, pos + 1);
+    if (B > 64) s->force_big_gemm = 1;                     // the general skinny kernel covers M <= 64 only
     CZCHK(llama_body(s, B, s->step_seqd, s->step_roped, B, 1, pos + 1, s->kv_layer_stride, s->pos_dev));
     return llama_head(s, s->step_rows, B, s->step_logits);
 }
@@ -330,6 +378,43 @@ static cz_status llama_reprime(cz_session* s, int B, int hl) {
     HIPCHK(hipStreamSynchronize(s->stream));       // host vectors go out of scope
     CZCHK(llama_body(s, B * hl, (const cz_seq_desc*)s->seqd.p, (const cz_rope_desc*)s->roped.p, B, hl, hl, s->kv_layer_stride, nullptr));
     return llama_head(s, (const int*)s->rowidx.p, B, s->step_logits);
+}
+
+// One decode iteration as a hipGraph: decode_symbol(i) -> tok = sym -> step(pos) -> ++i, ++pos.  All per-iteration scalars
+// live in HBM (pos_dev), so the same executable graph is replayed for every token; the host only enqueues.
+static void destroy_step_graph(cz_session* s) {
+    if (s->graph_exec) { hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
+    if (s->graph) { hipGraphDestroy(s->graph); s->graph = nullptr; }
+    s->graph_B = 0;
+}
+static cz_status build_step_graph(cz_session* s, int B) {
+    destroy_step_graph(s);
+    s->graph_gen = g_devbuf_gen;
+    const cz_llama_config& c = s->llama.cfg;
+    cz_dec_state* dst = (cz_dec_state*)s->decst.p;
+    const unsigned long long* step_dev = reinterpret_cast<const unsigned long long*>(s->pos_dev + 2);
+    const bool prof = s->prof_on; s->prof_on = false;            // no events inside a captured region
+    // every buffer the captured kernels touch must exist before capture starts
+    cz_status rc = llama_step_fast(s, B, 0, CZ_MAX_CTX);
+    if (rc != CZ_OK) { s->prof_on = prof; return rc; }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    hipError_t e = cz_launch_decode_symbol(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, 0ull, s->fallback_dev, step_dev);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->tok.p, s->step_sym, (size_t)B * 4, hipMemcpyDeviceToDevice, s->stream);
+    if (e == hipSuccess) rc = llama_step_fast(s, B, 0, CZ_MAX_CTX);
+    if (e == hipSuccess && rc == CZ_OK) { hipLaunchKernelGGL(inc_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev); e = hipGetLastError(); }
+    hipGraph_t g = nullptr;
+    hipError_t e2 = hipStreamEndCapture(s->stream, &g);
+    s->prof_on = prof;
+    if (e != hipSuccess || e2 != hipSuccess || rc != CZ_OK || !g) {
+        if (g) hipGraphDestroy(g);
+        cz_set_error("hipGraph capture of the decode step failed (%s / %s)", hipGetErrorString(e), hipGetErrorString(e2));
+        return CZ_ERR_HIP;
+    }
+    s->graph = g;
+    HIPCHK(hipGraphInstantiate(&s->graph_exec, s->graph, nullptr, nullptr, 0));
+    s->graph_B = B;
+    return CZ_OK;
 }
 
 // ------------------------------------------------------------------ schedule (the reference's re-prime predicate)
@@ -459,6 +544,17 @@ static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* 
     CZCHK(llama_step(s, B, 0));                                                              // step(bos) (:2485)
     size_t index_pos = 1;
     size_t ec = context_window > 0 ? context_window - 1 : 0; if (ec > 511) ec = 511;         // :2506
+    // graph replay unless per-kernel profiling of the decode families is requested or the graph path is disabled
+    const unsigned dec_kinds = (1u << PK_DECODE) | (1u << PK_DEC_GEMM) | (1u << PK_DEC_ATTN) | (1u << PK_DEC_NORM) | (1u << PK_EMBED);
+    const bool prof_decode = s->prof_on && (s->prof_mask & dec_kinds);
+    const bool use_graph = !s->no_graph && !s->decode_v1 && !s->serial_cdf && !prof_decode && c.n_heads / c.n_kv_heads <= 4;
+    if (use_graph && (s->graph_B != B || s->graph_gen != g_devbuf_gen)) {
+        CZCHK(build_step_graph(s, B));
+        if (s->graph_gen != g_devbuf_gen) CZCHK(build_step_graph(s, B));                     // the dry run itself grew a buffer: capture again
+        CZCHK(llama_step(s, B, 0));                                                          // the dry run clobbered the BOS logits
+    }
+    const unsigned long long* step_dev = reinterpret_cast<const unsigned long long*>(s->pos_dev + 2);
+    hipLaunchKernelGGL(set_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, (int)index_pos, 0ull);
     for (size_t i = 0; i < max_tc; ++i) {
         if (index_pos >= ec && (i % R) == 0 && i > 0) {                                      // :2532
             const size_t end = i + 1, hl = end > ec ? ec : end;                              // out_tokens.len() == i + 1
@@ -467,18 +563,25 @@ static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* 
                                (unsigned long long)end);
             CZCHK(llama_reprime(s, B, (int)hl));
             index_pos = hl;
+            hipLaunchKernelGGL(set_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, (int)index_pos, (unsigned long long)i);
         }
-        s->prof_begin(PK_DECODE);
-        if (s->serial_cdf) HIPCHK(cz_launch_decode_symbol_serial(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, (unsigned long long)i));
-        else HIPCHK(cz_launch_decode_symbol(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, (unsigned long long)i, s->fallback_dev));
-        s->prof_end(0, (double)B * c.vocab * 4);
-        if (i + 1 < max_tc) {
-            // the reference also steps after the last symbol (:2627); its logits are never used, so it is skipped here
-            HIPCHK(hipMemcpyAsync(s->tok.p, s->step_sym, (size_t)B * 4, hipMemcpyDeviceToDevice, s->stream));
-            CZCHK(llama_step(s, B, (int)index_pos));
+        if (index_pos >= (size_t)CZ_MAX_CTX) { cz_set_error("position %zu exceeds the supported context (%d)", index_pos, CZ_MAX_CTX); return CZ_ERR_STATE; }
+        if (use_graph) {
+            HIPCHK(hipGraphLaunch(s->graph_exec, s->stream));                                // decode_symbol(i); step(sym) at index_pos; ++i; ++pos
+        } else {
+            s->prof_begin(PK_DECODE);
+            if (s->serial_cdf) HIPCHK(cz_launch_decode_symbol_serial(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, (unsigned long long)i, nullptr));
+            else HIPCHK(cz_launch_decode_symbol(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, (unsigned long long)i, s->fallback_dev, nullptr));
+            s->prof_end(0, (double)B * c.vocab * 4);
+            if (i + 1 < max_tc) {
+                // the reference also steps after the last symbol (:2627); its logits are never used, so it is skipped here
+                HIPCHK(hipMemcpyAsync(s->tok.p, s->step_sym, (size_t)B * 4, hipMemcpyDeviceToDevice, s->stream));
+                CZCHK(llama_step(s, B, (int)index_pos));
+            }
         }
         index_pos += 1;
     }
+    (void)step_dev;
     std::vector<uint32_t> all(ids_total);
     HIPCHK(hipMemcpyAsync(all.data(), s->outids.p, ids_total * 4, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -500,7 +603,7 @@ extern "C" cz_status cz_session_open(const cz_model_desc* desc, int device_ordin
     cz_session* s = new cz_session();
     s->backend = desc->backend; s->device = device_ordinal; s->seed = desc->synthetic_seed;
     s->max_streams = desc->max_streams ? (int)desc->max_streams : 64;
-    if (s->max_streams > 64) { delete s; cz_set_error("max_streams > 64 is not supported"); return CZ_ERR_ARG; }
+    if (s->max_streams > 256) { delete s; cz_set_error("max_streams > 256 is not supported"); return CZ_ERR_ARG; }
     hipError_t e = hipStreamCreate(&s->stream);
     if (e != hipSuccess) { delete s; cz_set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return CZ_ERR_HIP; }
     if (hipMalloc((void**)&s->fallback_dev, 64) != hipSuccess || hipMemset(s->fallback_dev, 0, 64) != hipSuccess) { delete s; cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
@@ -508,6 +611,8 @@ extern "C" cz_status cz_session_open(const cz_model_desc* desc, int device_ordin
     if (desc->backend == CZ_BACKEND_SMOLLM) rc = build_llama(s, desc);
     else if (desc->backend == CZ_BACKEND_RWKV7) rc = cz_rwkv7_build(s, desc);
     else { cz_set_error("unknown backend %d", (int)desc->backend); rc = CZ_ERR_ARG; }      // src/main.rs:1829 "unknown backend"
+    if (rc == CZ_OK && desc->backend == CZ_BACKEND_SMOLLM && cz_cdf_par_prepare(s->llama.cfg.vocab) != hipSuccess) { cz_set_error("cannot allocate CDF scratch"); rc = CZ_ERR_HIP; }
+    if (rc == CZ_OK && cz_dec_attn_prepare(CZ_MAX_CTX) != hipSuccess) { cz_set_error("cannot reserve LDS for decode attention"); rc = CZ_ERR_HIP; }
     if (rc == CZ_OK && cz_attention_prepare(CZ_MAX_CTX) != hipSuccess) { cz_set_error("cannot reserve LDS for attention"); rc = CZ_ERR_HIP; }
     if (rc != CZ_OK) { cz_session_close(s); return rc; }
     *out = s;
@@ -517,12 +622,13 @@ extern "C" void cz_session_close(cz_session* s) {
     if (!s) return;
     hipSetDevice(s->device);
     if (s->stream) hipStreamSynchronize(s->stream);
+    destroy_step_graph(s);
     s->prof_drain();
     for (auto e : s->evt_free) hipEventDestroy(e);
     DevBuf* bufs[] = {&s->tok, &s->x, &s->xn, &s->qkv, &s->gu, &s->h, &s->seqd, &s->roped, &s->rowidx, &s->sym, &s->clo, &s->chi, &s->xl,
                       &s->logits, &s->payload, &s->outids, &s->decst};
     for (auto b : bufs) b->release();
-    void* ptrs[] = {s->fallback_dev, s->llama.blob, s->llama.rope_cos, s->llama.rope_sin, s->kvcache, s->pos_dev, s->step_seqd, s->step_roped, s->step_rows,
+    void* ptrs[] = {s->fallback_dev, s->llama.blob_dec, s->llama.blob, s->llama.rope_cos, s->llama.rope_sin, s->kvcache, s->pos_dev, s->step_seqd, s->step_roped, s->step_rows,
                     s->step_logits, s->step_sym};
     for (auto p : ptrs) if (p) { hipError_t e = hipFree(p); (void)e; }
     cz_rwkv7_destroy(s);
@@ -629,6 +735,8 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "max_batch_rows")) s->max_batch_rows = (size_t)value;
     else if (!strcmp(key, "logit_batch_rows")) s->logit_batch_rows = (size_t)value;
     else if (!strcmp(key, "serial_cdf")) s->serial_cdf = (int)value;
+    else if (!strcmp(key, "decode_v1")) s->decode_v1 = (int)value;
+    else if (!strcmp(key, "no_graph")) s->no_graph = (int)value;
     else { cz_set_error("unknown debug key %s", key); return CZ_ERR_ARG; }
     return CZ_OK;
 }

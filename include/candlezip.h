@@ -53,7 +53,7 @@ typedef struct cz_model_desc {
     float synthetic_embed_std;
     cz_llama_config llama;
     cz_rwkv7_config rwkv;
-    uint32_t max_streams;               /* capacity of the lock-step decode batch (0 => 64) */
+    uint32_t max_streams;               /* capacity of the lock-step decode batch (0 => 64, at most 256) */
 } cz_model_desc;
 
 typedef struct cz_session cz_session;

@@ -127,3 +127,23 @@ def test_smollm2_135m_shape_bitexact(cz, czo):
     outs = g.decode_tokens_batch([payload, payload[:]], [60, 60])
     assert np.array_equal(outs[0], ids) and np.array_equal(outs[1], ids)
     g.close(); o.close()
+
+
+def test_decode_paths_agree_graph_eager_v1(cz, czo, tiny_pair):
+    """hipGraph replay, eager fast kernels and the general (v1) kernels must decode identical ids"""
+    g, o = tiny_pair
+    rng = np.random.default_rng(8)
+    streams = [np.concatenate([[0], rng.integers(0, 512, n)]).astype(np.uint32) for n in (700, 300, 1200)]
+    pays = []
+    for s in streams:
+        lo, hi = g.encode_tokens(s)
+        pays.append(cz.ac_encode_pairs(lo, hi)[0])
+    for knobs in ({}, {"no_graph": 1}, {"decode_v1": 1}, {"serial_cdf": 1}):
+        for k, v in knobs.items():
+            g.debug_set(k, v)
+        outs = g.decode_tokens_batch(pays, [s.size - 1 for s in streams])
+        for k in knobs:
+            g.debug_set(k, 0)
+        for s, out in zip(streams, outs):
+            assert np.array_equal(s, out), knobs
+    assert g.debug_get("cdf_fallback_rows") == 0
