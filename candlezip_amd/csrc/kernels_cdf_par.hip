@@ -21,7 +21,7 @@
 #define T_PAR 1024
 #define LMAX 48
 #define NWAVE (T_PAR / 64)
-#define POOL_SLOTS 60
+#define POOL_SLOTS 48
 #define B_INVALID (-100000)
 #define B_EMPTY 100000
 
@@ -36,16 +36,21 @@ __device__ __forceinline__ uint32_t quantize_u(double acc) {   // src/main.rs:81
 }
 
 struct par_smem {
-    double D0[T_PAR], D1[T_PAR], acc_in[T_PAR];
-    int bexp[T_PAR];
+    double sD0[T_PAR], sD1[T_PAR];   // inclusive segmented scan of the chunk transducers (delta for start parity 0 / 1)
+    double segacc[T_PAR];            // exact acc at the start of the segment headed by chunk t; later: exact acc_in of chunk t
+    int bexp[T_PAR];                 // binade of a chunk's transducer, B_INVALID (no transducer) or B_EMPTY
+    unsigned char cls[T_PAR];        // 1 = provably clean (no copy kept), 0 = other
+    unsigned char sp[T_PAR];         // parities of sD0 / sD1 (bit 0 / bit 1) on the binade's grid
     unsigned char has_copy[T_PAR];   // 0 = none, 1..POOL = LDS pool slot + 1, 255 = global scratch
+    short heads[T_PAR];              // compacted list of segment-head chunks
+    short headof[T_PAR];             // head chunk of the segment a chunk belongs to
     double pool[POOL_SLOTS][LMAX];   // copies of the terms of chunks that are not provably clean (usually < 30 per row)
     unsigned pool_next;
-    double wsum[NWAVE], W0[NWAVE], W1[NWAVE], win[NWAVE];
-    int wb[NWAVE], wfast[NWAVE];
+    double wsum[NWAVE];
+    double wD0[NWAVE], wD1[NWAVE]; int wp[NWAVE], wflag[NWAVE], wcnt[NWAVE], whead[NWAVE];
     double total;
     float redf[NWAVE];
-    int flag, L, n;
+    int flag, L, n, nheads;
     unsigned found;
     uint32_t value, lo, hi;
     int ok;
@@ -64,11 +69,24 @@ __device__ __forceinline__ double block_excl_scan(double v, par_smem& sm) {     
     return base + inc - v;
 }
 
+// transducer composition "f then g" on one binade grid: out.D_p = f.D_p + g.D_{p xor parity(f.D_p)}
+struct tdx { double d0, d1; int p; };      // p: bit0 = parity(d0/u), bit1 = parity(d1/u)
+__device__ __forceinline__ tdx td_compose(const tdx& f, const tdx& g) {
+    const int q0 = f.p & 1, q1 = 1 ^ ((f.p >> 1) & 1);
+    tdx h;
+    h.d0 = f.d0 + (q0 ? g.d1 : g.d0);
+    h.d1 = f.d1 + (q1 ? g.d1 : g.d0);
+    const int g0 = g.p & 1, g1 = (g.p >> 1) & 1;
+    h.p = ((f.p & 1) ^ (q0 ? g1 : g0)) | ((((f.p >> 1) & 1) ^ (q1 ? g1 : g0)) << 1);
+    return h;
+}
+
 // Exact left-to-right sum of the block's terms xf(k) (thread t owns terms first..first+cnt-1, k < cnt <= LMAX).
 // Returns the exact total; with want_acc_in also the exact running sum before this thread's first term.
 // csum = APPROXIMATE sum of this thread's terms (any rounding; it only feeds the binade guesses).
 template <typename XF>
-__device__ __forceinline__ double exact_seq_sum(XF xf, double csum, int cnt, int first, par_smem& sm, double* scratch, bool want_acc_in, double* acc_in_out) {
+__device__ __forceinline__ double exact_seq_sum(XF xf, double csum, int cnt, int first, par_smem& sm, double* scratch, bool want_acc_in,
+                                                double* acc_in_out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) sm.pool_next = 0;
     const double pstart = block_excl_scan(csum, sm);            // (contains barriers: the reset above is visible afterwards)
@@ -92,7 +110,6 @@ __device__ __forceinline__ double exact_seq_sum(XF xf, double csum, int cnt, int
             }
         }
     }
-    sm.bexp[tid] = b; sm.D0[tid] = d0; sm.D1[tid] = d1;
     unsigned char where = 0;
     if (copy) {
         const unsigned slot = atomicAdd(&sm.pool_next, 1u);
@@ -106,62 +123,74 @@ __device__ __forceinline__ double exact_seq_sum(XF xf, double csum, int cnt, int
             for (int k = 0; k < LMAX; ++k) if (k < cnt) scratch[first + k] = xf(k);
         }
     }
-    sm.has_copy[tid] = where;
+    const bool clean = (b != B_INVALID && b != B_EMPTY && !copy);
+    sm.bexp[tid] = b; sm.has_copy[tid] = where; sm.cls[tid] = clean ? 1 : 0;
     __threadfence_block();
     __syncthreads();
-    if (lane == 0) {                                             // level 1: compose the wave's 64 transducers
-        int wbv = B_EMPTY; bool ok = true;
-        for (int j = 0; j < 64; ++j) {
-            const int bj = sm.bexp[wave * 64 + j];
-            if (bj == B_EMPTY) continue;
-            if (bj == B_INVALID) { ok = false; break; }
-            if (wbv == B_EMPTY) wbv = bj; else if (wbv != bj) { ok = false; break; }
-        }
-        double w0 = 0.0, w1 = 0.0;
-        if (ok && wbv != B_EMPTY) {
-            const double inv_u = pow2_f64(52 - wbv);
-            int p0 = 0, p1 = 1;
-            for (int j = 0; j < 64; ++j) {
-                const int t = wave * 64 + j;
-                if (sm.bexp[t] == B_EMPTY) continue;
-                const double a = p0 ? sm.D1[t] : sm.D0[t]; w0 += a; p0 ^= (int)((long long)(a * inv_u) & 1);
-                const double c = p1 ? sm.D1[t] : sm.D0[t]; w1 += c; p1 ^= (int)((long long)(c * inv_u) & 1);
-            }
-        }
-        sm.wb[wave] = ok ? wbv : B_INVALID; sm.W0[wave] = w0; sm.W1[wave] = w1;
+    // ---- segments: maximal runs of provably-clean chunks of one binade; every other non-empty chunk is a singleton
+    const bool nonempty = b != B_EMPTY;
+    bool head = nonempty;
+    if (clean && tid > 0 && sm.cls[tid - 1] && sm.bexp[tid - 1] == b) head = false;
+    tdx v; v.d0 = d0; v.d1 = d1; v.p = 0;
+    if (b != B_INVALID && b != B_EMPTY) {
+        const double inv_u = pow2_f64(52 - b);
+        v.p = (int)((long long)(d0 * inv_u) & 1) | ((int)((long long)(d1 * inv_u) & 1) << 1);
     }
+    // wave-level segmented inclusive scan (flag = "a head lies inside the range covered so far")
+    int flag = head ? 1 : 0;
+    int hidx = head ? tid : -1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        tdx u; u.d0 = __shfl_up(v.d0, o); u.d1 = __shfl_up(v.d1, o); u.p = __shfl_up(v.p, o);
+        const int uf = __shfl_up(flag, o), uh = __shfl_up(hidx, o);
+        if (lane >= o) {
+            if (!flag) v = td_compose(u, v);
+            flag |= uf;
+            hidx = hidx > uh ? hidx : uh;
+        }
+    }
+    // head count prefix (for compaction)
+    int hc = head ? 1 : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(hc, o); if (lane >= o) hc += y; }
+    if (lane == 63) { sm.wD0[wave] = v.d0; sm.wD1[wave] = v.d1; sm.wp[wave] = v.p; sm.wflag[wave] = flag; sm.wcnt[wave] = hc; sm.whead[wave] = hidx; }
     __syncthreads();
-    if (tid == 0) {                                              // level 2: ordered walk
+    {
+        // carry from the preceding waves (serial over <= NWAVE entries, every thread for itself: cheap, no extra barrier)
+        tdx carry; carry.d0 = 0.0; carry.d1 = 0.0; carry.p = 0; int have = 0, hbase = 0, chead = -1;
+        for (int w = 0; w < wave; ++w) {
+            tdx t; t.d0 = sm.wD0[w]; t.d1 = sm.wD1[w]; t.p = sm.wp[w];
+            if (sm.wflag[w]) { carry = t; have = 1; } else if (have) carry = td_compose(carry, t);
+            hbase += sm.wcnt[w];
+            if (sm.whead[w] > chead) chead = sm.whead[w];
+        }
+        if (!flag && have) v = td_compose(carry, v);
+        if (hidx < 0) hidx = chead;
+        if (head) sm.heads[hbase + hc - 1] = (short)tid;
+        if (tid == T_PAR - 1) sm.nheads = hbase + hc;
+    }
+    sm.sD0[tid] = v.d0; sm.sD1[tid] = v.d1; sm.sp[tid] = (unsigned char)v.p; sm.headof[tid] = (short)hidx;
+    __syncthreads();
+    // ---- ordered resolve over the segments (thread 0)
+    if (tid == 0) {
         double acc = 0.0;
-        const int L = sm.L, n = sm.n;
-        for (int w = 0; w < NWAVE; ++w) {
-            sm.win[w] = acc;
-            const int wbv = sm.wb[w];
-            if (wbv == B_EMPTY) { sm.wfast[w] = 1; continue; }
-            bool fast = false;
-            if (wbv != B_INVALID && acc > 0.0 && expo_f64(acc) == wbv) {
-                const double cand = acc + (parity_f64(acc) ? sm.W1[w] : sm.W0[w]);
-                if (cand < pow2_f64(wbv + 1)) { acc = cand; fast = true; }
+        const int L = sm.L, n = sm.n, nh = sm.nheads;
+        for (int i = 0; i < nh; ++i) {
+            const int t = sm.heads[i];
+            const int te = (i + 1 < nh ? (int)sm.heads[i + 1] : (n + L - 1) / L) - 1;     // last chunk of the segment
+            sm.segacc[t] = acc;
+            const int bj = sm.bexp[t];
+            bool done = false;
+            if (bj != B_INVALID && acc > 0.0 && expo_f64(acc) == bj) {
+                const double cand = acc + (parity_f64(acc) ? sm.sD1[te] : sm.sD0[te]);
+                if (cand < pow2_f64(bj + 1)) { acc = cand; done = true; }
             }
-            sm.wfast[w] = fast ? 1 : 0;
-            if (fast) continue;
-            for (int j = 0; j < 64; ++j) {
-                const int t = w * 64 + j;
-                sm.acc_in[t] = acc;
-                const int bj = sm.bexp[t];
-                if (bj == B_EMPTY) continue;
-                bool done = false;
-                if (bj != B_INVALID && acc > 0.0 && expo_f64(acc) == bj) {
-                    const double cand = acc + (parity_f64(acc) ? sm.D1[t] : sm.D0[t]);
-                    if (cand < pow2_f64(bj + 1)) { acc = cand; done = true; }
-                }
-                if (!done) {
-                    const int wh = sm.has_copy[t];
-                    if (!wh) { sm.flag = 1; continue; }
-                    const int f0 = t * L, c = n - f0 < L ? n - f0 : L;
-                    if (wh != 255) { const double* src = sm.pool[wh - 1]; for (int k = 0; k < c; ++k) acc = acc + src[k]; }   // the chunk's true chain
-                    else for (int k = 0; k < c; ++k) acc = acc + scratch[f0 + k];           // pool exhausted (rare): global copy
-                }
+            if (!done) {
+                const int wh = sm.has_copy[t];
+                if (!wh) { sm.flag = 1; continue; }                  // a "provably clean" segment failed its check: serial fallback
+                const int f0 = t * L, c = n - f0 < L ? n - f0 : L;
+                if (wh != 255) { const double* src = sm.pool[wh - 1]; for (int k = 0; k < c; ++k) acc = acc + src[k]; }   // the chunk's true chain
+                else for (int k = 0; k < c; ++k) acc = acc + scratch[f0 + k];           // pool exhausted (rare): global copy
             }
         }
         sm.total = acc;
@@ -169,17 +198,13 @@ __device__ __forceinline__ double exact_seq_sum(XF xf, double csum, int cnt, int
     __syncthreads();
     const double total = sm.total;
     if (want_acc_in) {
-        if (lane == 0 && sm.wfast[wave] && sm.wb[wave] != B_EMPTY) {   // level 1': replay skipped waves from their exact start
-            double acc = sm.win[wave];
-            for (int j = 0; j < 64; ++j) {
-                const int t = wave * 64 + j;
-                sm.acc_in[t] = acc;
-                if (sm.bexp[t] == B_EMPTY) continue;
-                acc = acc + (parity_f64(acc) ? sm.D1[t] : sm.D0[t]);
-            }
+        double a = 0.0;
+        if (nonempty) {
+            const int h = sm.headof[tid];
+            a = sm.segacc[h];
+            if (h != tid) a = a + (parity_f64(a) ? sm.sD1[tid - 1] : sm.sD0[tid - 1]);   // exclusive prefix inside the clean segment
         }
-        __syncthreads();
-        *acc_in_out = sm.acc_in[tid];
+        *acc_in_out = a;
     }
     __syncthreads();
     return total;
