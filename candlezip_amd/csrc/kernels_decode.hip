@@ -33,43 +33,40 @@ hipError_t cz_launch_dec_pack(hipStream_t st, const uint16_t* W, uint16_t* Wd, s
     return hipGetLastError();
 }
 
-// RMSNorm for the decode path: same arithmetic as rmsnorm_kernel, output in kq layout (feeds dec_gemm_kernel)
-__global__ __launch_bounds__(256) void dec_rmsnorm_kernel(const float* __restrict__ X, int ldx, const uint16_t* __restrict__ w,
-                                                          float* __restrict__ Y, int ldy, int M, int d, float eps) {
-    __shared__ float part[16][17];
-    __shared__ float mval[16];
-    const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
-    const int m = blockIdx.x * 16 + r;
-    const int nch = d / 64;
-    if (m < M && c < nch) {
+// RMSNorm for the decode path: same arithmetic as rmsnorm_kernel, output in kq layout (feeds dec_gemm_kernel).
+// One block per row, one thread per element (d <= 1024); lane 0 of wave c walks chunk c's canonical 64-sum.
+__global__ __launch_bounds__(1024) void dec_rmsnorm_kernel(const float* __restrict__ X, int ldx, const uint16_t* __restrict__ w,
+                                                           float* __restrict__ Y, int ldy, int M, int d, float eps) {
+    __shared__ float part[16];
+    __shared__ float mval;
+    const int tid = threadIdx.x, lane = tid & 63, c = tid >> 6;
+    const int m = blockIdx.x;
+    const float xv = X[(size_t)m * ldx + tid];
+    if (lane == 0) {
         float p = 0.0f;
         const f32x4* src = reinterpret_cast<const f32x4*>(X + (size_t)m * ldx + c * 64);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            f32x4 v = src[k];
-            float s0 = v[0] * v[0], s1 = v[1] * v[1], s2 = v[2] * v[2], s3 = v[3] * v[3];
+            const f32x4 v = src[k];
+            const float s0 = v[0] * v[0], s1 = v[1] * v[1], s2 = v[2] * v[2], s3 = v[3] * v[3];
             p = p + s0; p = p + s1; p = p + s2; p = p + s3;
         }
-        part[r][c] = p;
+        part[c] = p;
     }
     __syncthreads();
-    if (m < M && c == 0) {
-        float t = part[r][0];
-        for (int k = 1; k < nch; ++k) t = t + part[r][k];
-        mval[r] = sqrtf(t / (float)d + eps);
+    if (tid == 0) {
+        const int nch = d >> 6;
+        float t = part[0];
+        for (int k = 1; k < nch; ++k) t = t + part[k];
+        mval = sqrtf(t / (float)d + eps);
     }
     __syncthreads();
-    for (int i = tid; i < 16 * d; i += 256) {
-        const int rr = i / d, k = i % d;
-        const int mm = blockIdx.x * 16 + rr;
-        if (mm >= M) break;
-        const float v = X[(size_t)mm * ldx + k];
-        Y[(size_t)mm * ldy + kq_index(k)] = v / mval[rr] * cz_bf16_to_f32(w[k]);
-    }
+    Y[(size_t)m * ldy + kq_index(tid)] = xv / mval * cz_bf16_to_f32(w[tid]);
 }
 hipError_t cz_launch_dec_rmsnorm(hipStream_t st, const float* X, int ldx, const uint16_t* w, float* Y, int ldy, int M, int d, float eps) {
     if (M <= 0) return hipSuccess;
-    hipLaunchKernelGGL(dec_rmsnorm_kernel, dim3((M + 15) / 16), dim3(256), 0, st, X, ldx, w, Y, ldy, M, d, eps);
+    if (d % 64 || d > 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dec_rmsnorm_kernel, dim3(M), dim3(d), 0, st, X, ldx, w, Y, ldy, M, d, eps);
     return hipGetLastError();
 }
 
@@ -87,15 +84,16 @@ struct dec_gemm_args {
     const cz_rope_desc* descs; size_t kv_off; const int* pos_dev; const float* cs; const float* sn;
 };
 
-template <int EPI, int NORM>
+// MT = 16-row tiles per block (1, 2, 4, 8): one load of the weight slab serves MT x 16 rows.
+template <int EPI, int NORM, int MT>
 __global__ __launch_bounds__(768) void dec_gemm_kernel(dec_gemm_args a) {
-    extern __shared__ __attribute__((aligned(16))) float part[];       // [NW][2][16][17]
-    __shared__ float nsq[16][17];
-    __shared__ float nm[16];
+    extern __shared__ __attribute__((aligned(16))) float part[];       // [NW][G][2][16][17], G = min(MT, 2) row tiles per reduction round
+    __shared__ float nsq[MT * 16][17];
+    __shared__ float nm[MT * 16];
+    constexpr int G = MT < 2 ? MT : 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    const int m0 = blockIdx.y * 16;
-    // column tiles of this block
+    const int m0 = blockIdx.y * (MT * 16);
     int n0, n1;
     if (EPI == EPI_ROPE) {                       // pair (c, c+32) inside one 64-wide head; v heads: two plain tiles of the same head
         const int head = blockIdx.x >> 1, j = blockIdx.x & 1;
@@ -106,11 +104,10 @@ __global__ __launch_bounds__(768) void dec_gemm_kernel(dec_gemm_args a) {
         n0 = blockIdx.x * 32; n1 = n0 + 16;
     }
     const int K = a.K, nch = K >> 6;
-    const int arow = m0 + li;
     if (NORM) {
         // candle rms_norm: m = sqrt(sum(x*x)/d + eps) with the canonical chunk-64 sum; y = x / m * w   (K <= 1024)
-        if (tid < 16 * nch) {
-            const int r = tid / nch, c = tid % nch;
+        for (int task = tid; task < MT * 16 * nch; task += blockDim.x) {
+            const int r = task / nch, c = task % nch;
             float p = 0.0f;
             if (m0 + r < a.M) {
                 const f32x4* src = reinterpret_cast<const f32x4*>(a.A + (size_t)(m0 + r) * a.lda + c * 64);
@@ -124,103 +121,145 @@ __global__ __launch_bounds__(768) void dec_gemm_kernel(dec_gemm_args a) {
             nsq[r][c] = p;
         }
         __syncthreads();
-        if (tid < 16) {
+        if (tid < MT * 16) {
             float t = nsq[tid][0];
             for (int k = 1; k < nch; ++k) t = t + nsq[tid][k];
             nm[tid] = sqrtf(t / (float)K + a.eps);
         }
         __syncthreads();
     }
-    float tot0 = 0.0f, tot1 = 0.0f;              // element (r = tid >> 4, c = tid & 15) of both tiles, owned by threads 0..255
+    float tot0[MT], tot1[MT];                    // element (r = tid >> 4, c = tid & 15) of both column tiles of row tile m; threads 0..255
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { tot0[m] = 0.0f; tot1[m] = 0.0f; }
     for (int c0 = 0; c0 < nch; c0 += NW) {
         const int c = c0 + wave;
+        f32x4 acc0[MT], acc1[MT];
         if (c < nch) {
-            f32x4 av[4];
-            if (arow >= a.M) { av[0] = av[1] = av[2] = av[3] = f32x4{0, 0, 0, 0}; }
-            else if (NORM) {
-                const float* xr = a.A + (size_t)arow * a.lda + c * 64 + lg;        // natural layout: k = 4t + g
-                const uint16_t* wr = a.normw + c * 64 + lg;
-                const float mv = nm[li];
-#pragma unroll
-                for (int t = 0; t < 16; ++t) av[t >> 2][t & 3] = xr[4 * t] / mv * cz_bf16_to_f32(wr[4 * t]);
-            } else {
-                const f32x4* ap = reinterpret_cast<const f32x4*>(a.A + (size_t)arow * a.lda + c * 64 + lg * 16);
-                av[0] = ap[0]; av[1] = ap[1]; av[2] = ap[2]; av[3] = ap[3];
-            }
             const uint4* b0p = reinterpret_cast<const uint4*>(a.Wd + (size_t)(n0 + li) * K + c * 64 + lg * 16);
             const uint4* b1p = reinterpret_cast<const uint4*>(a.Wd + (size_t)(n1 + li) * K + c * 64 + lg * 16);
             const uint4 b0a = b0p[0], b0b = b0p[1], b1a = b1p[0], b1b = b1p[1];
             const unsigned w0[8] = {b0a.x, b0a.y, b0a.z, b0a.w, b0b.x, b0b.y, b0b.z, b0b.w};
             const unsigned w1[8] = {b1a.x, b1a.y, b1a.z, b1a.w, b1b.x, b1b.y, b1b.z, b1b.w};
-            f32x4 acc0 = f32x4{0, 0, 0, 0}, acc1 = f32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float av_t = av[t >> 2][t & 3];
-                const float bv0 = (t & 1) ? cz_bits_f32(w0[t >> 1] & 0xffff0000u) : cz_bits_f32(w0[t >> 1] << 16);
-                const float bv1 = (t & 1) ? cz_bits_f32(w1[t >> 1] & 0xffff0000u) : cz_bits_f32(w1[t >> 1] << 16);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av_t, bv0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av_t, bv1, acc1, 0, 0, 0);
-            }
-            float* p = part + wave * (2 * 16 * 17);
+            for (int m = 0; m < MT; ++m) {
+                const int arow = m0 + m * 16 + li;
+                f32x4 av[4];
+                if (arow >= a.M) { av[0] = av[1] = av[2] = av[3] = f32x4{0, 0, 0, 0}; }
+                else if (NORM) {
+                    const float* xr = a.A + (size_t)arow * a.lda + c * 64 + lg;        // natural layout: k = 4t + g
+                    const uint16_t* wr = a.normw + c * 64 + lg;
+                    const float mv = nm[m * 16 + li];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {       // C/D: col = li, row = 4*lg + r
-                p[(4 * lg + r) * 17 + li] = acc0[r];
-                p[16 * 17 + (4 * lg + r) * 17 + li] = acc1[r];
+                    for (int t = 0; t < 16; ++t) av[t >> 2][t & 3] = xr[4 * t] / mv * cz_bf16_to_f32(wr[4 * t]);
+                } else {
+                    const f32x4* ap = reinterpret_cast<const f32x4*>(a.A + (size_t)arow * a.lda + c * 64 + lg * 16);
+                    av[0] = ap[0]; av[1] = ap[1]; av[2] = ap[2]; av[3] = ap[3];
+                }
+                f32x4 x0 = f32x4{0, 0, 0, 0}, x1 = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const float av_t = av[t >> 2][t & 3];
+                    const float bv0 = (t & 1) ? cz_bits_f32(w0[t >> 1] & 0xffff0000u) : cz_bits_f32(w0[t >> 1] << 16);
+                    const float bv1 = (t & 1) ? cz_bits_f32(w1[t >> 1] & 0xffff0000u) : cz_bits_f32(w1[t >> 1] << 16);
+                    x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av_t, bv0, x0, 0, 0, 0);
+                    x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av_t, bv1, x1, 0, 0, 0);
+                }
+                acc0[m] = x0; acc1[m] = x1;
             }
         }
-        __syncthreads();
-        if (tid < 256) {
-            const int r = tid >> 4, cc = tid & 15;
-            const int lim = nch - c0 < NW ? nch - c0 : NW;
-            for (int w = 0; w < lim; ++w) {
-                const float p0 = part[w * (2 * 16 * 17) + r * 17 + cc], p1 = part[w * (2 * 16 * 17) + 16 * 17 + r * 17 + cc];
-                if (c0 + w == 0) { tot0 = p0; tot1 = p1; } else { tot0 = tot0 + p0; tot1 = tot1 + p1; }
+        // ordered reduction of the chunk partials, G row tiles per round
+#pragma unroll
+        for (int mg = 0; mg < MT; mg += G) {
+            if (c < nch) {
+                float* p = part + wave * (G * 2 * 16 * 17);
+#pragma unroll
+                for (int q = 0; q < G; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {       // C/D: col = li, row = 4*lg + r
+                        p[(q * 2 + 0) * 272 + (4 * lg + r) * 17 + li] = acc0[mg + q][r];
+                        p[(q * 2 + 1) * 272 + (4 * lg + r) * 17 + li] = acc1[mg + q][r];
+                    }
             }
+            __syncthreads();
+            if (tid < 256) {
+                const int r = tid >> 4, cc = tid & 15;
+                const int lim = nch - c0 < NW ? nch - c0 : NW;
+#pragma unroll
+                for (int q = 0; q < G; ++q)
+                    for (int w = 0; w < lim; ++w) {
+                        const float p0 = part[w * (G * 544) + (q * 2 + 0) * 272 + r * 17 + cc];
+                        const float p1 = part[w * (G * 544) + (q * 2 + 1) * 272 + r * 17 + cc];
+                        if (c0 + w == 0) { tot0[mg + q] = p0; tot1[mg + q] = p1; } else { tot0[mg + q] = tot0[mg + q] + p0; tot1[mg + q] = tot1[mg + q] + p1; }
+                    }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (tid >= 256) return;
-    const int r = tid >> 4, cc = tid & 15, row = m0 + r;
-    if (row >= a.M) return;
-    if (EPI == EPI_PLAIN) {
-        float v0 = tot0, v1 = tot1;
-        if (a.R) { v0 = v0 + a.R[(size_t)row * a.ldc + n0 + cc]; v1 = v1 + a.R[(size_t)row * a.ldc + n1 + cc]; }
-        a.C[(size_t)row * a.ldc + n0 + cc] = v0;
-        a.C[(size_t)row * a.ldc + n1 + cc] = v1;
-    } else if (EPI == EPI_SWIGLU) {
-        a.C[(size_t)row * a.ldc + kq_index(n0 + cc)] = cz_siluf(tot0) * tot1;      // silu(gate) * up  (llama.rs MLP)
-    } else {
-        cz_rope_desc d = a.descs[row];           // one row per stream
-        const int pos = a.pos_dev ? *a.pos_dev : d.pos0;
-        const int head = n0 >> 6, i = (n0 & 63) + cc;                             // rotation index i in [0, 32)
-        if (head < a.n_heads + a.n_kv) {
-            const float c_ = a.cs[(size_t)pos * 32 + i], s_ = a.sn[(size_t)pos * 32 + i];
-            const float x1 = tot0, x2 = tot1;
-            const float aa = x1 * c_, bb = x2 * s_, c2 = x1 * s_, dd = x2 * c_;      // candle rope: products rounded separately
-            const float o1 = aa - bb, o2 = c2 + dd;
-            if (head < a.n_heads) {
-                a.C[(size_t)row * a.ldc + head * 64 + i] = o1; a.C[(size_t)row * a.ldc + head * 64 + i + 32] = o2;
-            } else {
-                float* kd = d.k_dst + a.kv_off + (size_t)pos * d.dst_stride + (head - a.n_heads) * 64;
-                kd[i] = o1; kd[i + 32] = o2;
-            }
+    const int r = tid >> 4, cc = tid & 15;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int row = m0 + m * 16 + r;
+        if (row >= a.M) continue;
+        const float t0 = tot0[m], t1 = tot1[m];
+        if (EPI == EPI_PLAIN) {
+            float v0 = t0, v1 = t1;
+            if (a.R) { v0 = v0 + a.R[(size_t)row * a.ldc + n0 + cc]; v1 = v1 + a.R[(size_t)row * a.ldc + n1 + cc]; }
+            a.C[(size_t)row * a.ldc + n0 + cc] = v0;
+            a.C[(size_t)row * a.ldc + n1 + cc] = v1;
+        } else if (EPI == EPI_SWIGLU) {
+            a.C[(size_t)row * a.ldc + kq_index(n0 + cc)] = cz_siluf(t0) * t1;      // silu(gate) * up  (llama.rs MLP)
         } else {
-            float* vd = d.v_dst + a.kv_off + (size_t)pos * d.dst_stride + (head - a.n_heads - a.n_kv) * 64;
-            vd[i] = tot0; vd[i + 32] = tot1;
+            cz_rope_desc d = a.descs[row];           // one row per stream
+            const int pos = a.pos_dev ? *a.pos_dev : d.pos0;
+            const int head = n0 >> 6, i = (n0 & 63) + cc;                             // rotation index i in [0, 32)
+            if (head < a.n_heads + a.n_kv) {
+                const float c_ = a.cs[(size_t)pos * 32 + i], s_ = a.sn[(size_t)pos * 32 + i];
+                const float aa = t0 * c_, bb = t1 * s_, c2 = t0 * s_, dd = t1 * c_;      // candle rope: products rounded separately
+                const float o1 = aa - bb, o2 = c2 + dd;
+                if (head < a.n_heads) {
+                    a.C[(size_t)row * a.ldc + head * 64 + i] = o1; a.C[(size_t)row * a.ldc + head * 64 + i + 32] = o2;
+                } else {
+                    float* kd = d.k_dst + a.kv_off + (size_t)pos * d.dst_stride + (head - a.n_heads) * 64;
+                    kd[i] = o1; kd[i + 32] = o2;
+                }
+            } else {
+                float* vd = d.v_dst + a.kv_off + (size_t)pos * d.dst_stride + (head - a.n_heads - a.n_kv) * 64;
+                vd[i] = t0; vd[i + 32] = t1;
+            }
         }
     }
 }
 
 static int dec_nw(int K) { int nch = K / 64; nch = nch < 12 ? nch : 12; return nch < 4 ? 4 : nch; }   // >= 256 threads: one per element of a tile
+template <int EPI, int NORM, int MT>
+static hipError_t dec_gemm_launch_mt(hipStream_t st, const dec_gemm_args& a, int gx) {
+    const int NW = dec_nw(a.K);
+    const int G = MT < 2 ? MT : 2;
+    const size_t smem = (size_t)NW * G * 2 * 16 * 17 * sizeof(float);
+    hipLaunchKernelGGL((dec_gemm_kernel<EPI, NORM, MT>), dim3(gx, (a.M + MT * 16 - 1) / (MT * 16)), dim3(64 * NW), smem, st, a);
+    return hipGetLastError();
+}
+template <int EPI, int NORM>
+static hipError_t dec_gemm_launch_n(hipStream_t st, const dec_gemm_args& a, int gx) {
+    // row tiles per block: keep the grid near one wave of blocks (<= ~384) while it still has >= 64 of them
+    const int mt_all = (a.M + 15) / 16;
+    int mt = 1;
+    while (mt < 8 && mt < mt_all && (long)gx * ((mt_all + mt - 1) / mt) > 384) mt *= 2;
+    switch (mt) {
+        case 1: return dec_gemm_launch_mt<EPI, NORM, 1>(st, a, gx);
+        case 2: return dec_gemm_launch_mt<EPI, NORM, 2>(st, a, gx);
+        case 4: return dec_gemm_launch_mt<EPI, NORM, 4>(st, a, gx);
+        default: return dec_gemm_launch_mt<EPI, NORM, 8>(st, a, gx);
+    }
+}
 template <int EPI>
 static hipError_t dec_gemm_launch(hipStream_t st, const dec_gemm_args& a, int gx) {
-    const int NW = dec_nw(a.K);
-    const size_t smem = (size_t)NW * 2 * 16 * 17 * sizeof(float);
     if (a.normw) {
         if (a.K > 1024) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((dec_gemm_kernel<EPI, 1>), dim3(gx, (a.M + 15) / 16), dim3(64 * NW), smem, st, a);
-    } else hipLaunchKernelGGL((dec_gemm_kernel<EPI, 0>), dim3(gx, (a.M + 15) / 16), dim3(64 * NW), smem, st, a);
-    return hipGetLastError();
+        return dec_gemm_launch_n<EPI, 1>(st, a, gx);
+    }
+    return dec_gemm_launch_n<EPI, 0>(st, a, gx);
 }
 // C[M][N] (natural) = A(kq) . W^T (+ R)
 hipError_t cz_launch_dec_gemm_plain(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* C, int ldc, const float* R, int M, int N, int K,

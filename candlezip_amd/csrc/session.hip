@@ -326,7 +326,7 @@ static cz_status llama_step_fast(cz_session* s, int B, int pos, int max_nk) {
     const int d = c.d_model, f = c.d_ffn;
     CZCHK(s->x.ensure((size_t)B * d * 4)); CZCHK(s->xn.ensure((size_t)B * d * 4)); CZCHK(s->qkv.ensure((size_t)B * d * 4));
     CZCHK(s->gu.ensure((size_t)B * d * 4)); CZCHK(s->h.ensure((size_t)B * f * 4));
-    float *x = (float*)s->x.p, *q = (float*)s->qkv.p, *att = (float*)s->gu.p, *h = (float*)s->h.p;
+    float *x = (float*)s->x.p, *xn = (float*)s->xn.p, *q = (float*)s->qkv.p, *att = (float*)s->gu.p, *h = (float*)s->h.p;
     hipStream_t st = s->stream;
     auto dec = [&](const uint16_t* w) { return m.blob_dec + (w - m.blob); };
     s->prof_begin(PK_EMBED); HIPCHK(cz_launch_embed(st, (const uint32_t*)s->tok.p, m.E, x, B, d)); s->prof_end(0, (double)B * d * 6);
@@ -342,11 +342,14 @@ static cz_status llama_step_fast(cz_session* s, int B, int pos, int max_nk) {
         HIPCHK(cz_launch_dec_attn(st, q, d, att, d, s->step_seqd, B, max_nk, c.n_heads, c.n_kv_heads, kv_off, s->pos_dev));
         s->prof_end(4.0 * 64 * c.n_heads * (double)B * (pos + 1), 2.0 * B * (double)(pos + 1) * kvd * 4);
         s->prof_begin(PK_DEC_GEMM); HIPCHK(cz_launch_dec_gemm_plain(st, att, d, dec(y.wo), x, d, x, B, d, d, nullptr, 0.0f)); s->prof_end(2.0 * B * (double)d * d, (double)d * d * 2);
-        s->prof_begin(PK_DEC_GEMM); HIPCHK(cz_launch_dec_gemm_swiglu(st, x, d, dec(y.wgu), h, f, B, f, d, y.ln2, c.rms_eps)); s->prof_end(4.0 * B * (double)f * d, (double)f * d * 4);
+        // wide projections (gate|up, lm_head) have many column blocks: normalise once instead of once per block
+        s->prof_begin(PK_DEC_NORM); HIPCHK(cz_launch_dec_rmsnorm(st, x, d, y.ln2, xn, d, B, d, c.rms_eps)); s->prof_end(0, (double)B * d * 8);
+        s->prof_begin(PK_DEC_GEMM); HIPCHK(cz_launch_dec_gemm_swiglu(st, xn, d, dec(y.wgu), h, f, B, f, d, nullptr, 0.0f)); s->prof_end(4.0 * B * (double)f * d, (double)f * d * 4);
         s->prof_begin(PK_DEC_GEMM); HIPCHK(cz_launch_dec_gemm_plain(st, h, f, dec(y.wd), x, d, x, B, d, f, nullptr, 0.0f)); s->prof_end(2.0 * B * (double)d * f, (double)d * f * 2);
     }
-    s->prof_begin(PK_DEC_GEMM);                                                            // final RMSNorm fused into the lm_head
-    HIPCHK(cz_launch_dec_gemm_plain(st, x, d, dec(m.E), s->step_logits, c.vocab, nullptr, B, c.vocab, d, m.lnf, c.rms_eps));
+    s->prof_begin(PK_DEC_NORM); HIPCHK(cz_launch_dec_rmsnorm(st, x, d, m.lnf, xn, d, B, d, c.rms_eps)); s->prof_end(0, (double)B * d * 8);
+    s->prof_begin(PK_DEC_GEMM);
+    HIPCHK(cz_launch_dec_gemm_plain(st, xn, d, dec(m.E), s->step_logits, c.vocab, nullptr, B, c.vocab, d, nullptr, 0.0f));
     s->prof_end(2.0 * B * (double)c.vocab * d, (double)c.vocab * d * 2 + (double)B * c.vocab * 4);
     return CZ_OK;
 }
