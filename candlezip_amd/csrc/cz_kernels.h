@@ -10,6 +10,8 @@ struct cz_seq_desc {
     int row0, nrows, pos0, kv_stride;
     const float* k;
     const float* v;
+    int kt_stride;      // 0: K rows like V (k[j*kv_stride + kvh*64 + d]); > 0: K transposed, k[(kvh*64 + d)*kt_stride + j] (the decode KV cache:
+    int pad_;           //    lane = key then reads 64 consecutive floats per d -> fully coalesced)
 };
 
 // rows [row0, row0+nrows) are RoPE'd at positions pos0..; K (RoPE'd) and V are written to k_dst/v_dst rows pos0..
@@ -17,6 +19,8 @@ struct cz_rope_desc {
     int row0, nrows, pos0, dst_stride;
     float* k_dst;
     float* v_dst;
+    int kt_stride;      // as in cz_seq_desc
+    int pad_;
 };
 
 hipError_t cz_launch_gemm(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R, int ldr,

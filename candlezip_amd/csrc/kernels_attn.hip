@@ -64,7 +64,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
             const int key = i >> 4, q4 = i & 15;
             const int j = c * 64 + key;
             f32x4 v = f32x4{0, 0, 0, 0};
-            if (j < nk_blk) v = *reinterpret_cast<const f32x4*>(sd.k + (size_t)j * sd.kv_stride + kvh * 64 + q4 * 4);
+            if (j < nk_blk) {
+                if (sd.kt_stride) {
+                    const float* kp = sd.k + (size_t)(kvh * 64 + q4 * 4) * sd.kt_stride + j;
+                    v = f32x4{kp[0], kp[sd.kt_stride], kp[2 * (size_t)sd.kt_stride], kp[3 * (size_t)sd.kt_stride]};
+                } else v = *reinterpret_cast<const f32x4*>(sd.k + (size_t)j * sd.kv_stride + kvh * 64 + q4 * 4);
+            }
             *reinterpret_cast<f32x4*>(stage + key * KS + q4 * 4) = v;
         }
         __syncthreads();

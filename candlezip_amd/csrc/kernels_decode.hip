@@ -219,6 +219,9 @@ __global__ __launch_bounds__(768) void dec_gemm_kernel(dec_gemm_args a) {
                 const float o1 = aa - bb, o2 = c2 + dd;
                 if (head < a.n_heads) {
                     a.C[(size_t)row * a.ldc + head * 64 + i] = o1; a.C[(size_t)row * a.ldc + head * 64 + i + 32] = o2;
+                } else if (d.kt_stride) {
+                    float* kd = d.k_dst + a.kv_off + (size_t)((head - a.n_heads) * 64) * d.kt_stride + pos;
+                    kd[(size_t)i * d.kt_stride] = o1; kd[(size_t)(i + 32) * d.kt_stride] = o2;
                 } else {
                     float* kd = d.k_dst + a.kv_off + (size_t)pos * d.dst_stride + (head - a.n_heads) * 64;
                     kd[i] = o1; kd[i + 32] = o2;
@@ -289,102 +292,156 @@ hipError_t cz_launch_dec_gemm_swiglu(hipStream_t st, const float* A, int lda, co
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// decode attention: block = (stream, kv head), 512 threads.  Same arithmetic as attention_kernel.
+// decode attention: block = (stream, kv head), 512 threads (8 waves).  Same arithmetic as attention_kernel.
+// Wave w owns key chunks w, w+8, ... through all phases (scores stay in registers), so only three block barriers are
+// needed: after the local maxima, after the chunk sums, after the chunk partials of P.V.
+// HBM-bound: algorithmic bytes = 2 * nk * 256 B per block (K and V rows of the group's kv head, f32).
 #define DA_THREADS 512
+#define DA_WAVES (DA_THREADS / 64)
 #define DA_MAXREP 4
+#define DA_MAXC 4                                 // chunks per wave: 8 * 4 * 64 = 2048 keys
+typedef __attribute__((address_space(1))) const float gfloat;     // K/V pointers come out of a descriptor in memory: tell the
+                                                                  // compiler they are global (global_load, not flat_load)
+template <int rep>   // query heads per kv head: compile-time so that the per-head code carries no branches
 __global__ __launch_bounds__(DA_THREADS) void dec_attn_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
                                                               const cz_seq_desc* __restrict__ descs, int n_heads, int n_kv, int s_stride,
                                                               size_t kv_off, const int* __restrict__ pos_dev) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     cz_seq_desc sd = descs[blockIdx.x];
     const int pos = pos_dev ? *pos_dev : sd.pos0;
-    const int nk = pos + 1, nch = (nk + 63) >> 6, nkp = nch * 64;
-    const int kvh = blockIdx.y, rep = n_heads / n_kv;
-    const float* Kb = sd.k + kv_off + kvh * 64;
-    const float* Vb = sd.v + kv_off + kvh * 64;
+    const int nk = pos + 1, nch = (nk + 63) >> 6;
+    const int kvh = blockIdx.y;
+    gfloat* Kb = (gfloat*)(sd.k + kv_off + (sd.kt_stride ? (size_t)kvh * 64 * sd.kt_stride : (size_t)kvh * 64));
+    gfloat* Vb = (gfloat*)(sd.v + kv_off + kvh * 64);
     float* qs = smem;                                   // [DA_MAXREP][64]
-    float* S = qs + DA_MAXREP * 64;                     // [rep][s_stride]
-    float* part = S + DA_MAXREP * s_stride;             // [nch][DA_MAXREP][64]
-    float* red = part + 32 * DA_MAXREP * 64;            // [DA_MAXREP][32] + [DA_MAXREP]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NWV = DA_THREADS / 64;
+    float* S = qs + DA_MAXREP * 64;                     // [DA_MAXREP][s_stride]  e, then p
+    float* part = S + DA_MAXREP * s_stride;             // [32][DA_MAXREP][64]   chunk partials of P.V
+    float* red = part + 32 * DA_MAXREP * 64;            // [DA_WAVES][DA_MAXREP] local maxima
+    float* csum = red + DA_WAVES * DA_MAXREP;           // [DA_MAXREP][32]       chunk sums of e
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < rep * 64) qs[tid] = Q[(size_t)sd.row0 * ldq + (kvh * rep + (tid >> 6)) * 64 + (tid & 63)];
     __syncthreads();
-    // scores: lane = key
-    for (int c = wave; c < nch; c += NWV) {
-        const int j = c * 64 + lane;
-        float s[DA_MAXREP] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (j < nk) {
-            const f32x4* kr = reinterpret_cast<const f32x4*>(Kb + (size_t)j * sd.kv_stride);
+    // ---- phase 1: scores of the wave's chunks (lane = key), kept in registers
+    float sc[DA_MAXC][DA_MAXREP];
+    float lm[DA_MAXREP] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-            for (int q4 = 0; q4 < 16; ++q4) {
-                const f32x4 kv = kr[q4];
+    for (int i = 0; i < DA_MAXC; ++i) {
+        const int c = wave + DA_WAVES * i;
 #pragma unroll
-                for (int h = 0; h < DA_MAXREP; ++h)
-                    if (h < rep) {
-                        const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + h * 64 + q4 * 4);
-                        s[h] = cz_fma(qv[0], kv[0], s[h]); s[h] = cz_fma(qv[1], kv[1], s[h]);
-                        s[h] = cz_fma(qv[2], kv[2], s[h]); s[h] = cz_fma(qv[3], kv[3], s[h]);
-                    }
+        for (int h = 0; h < DA_MAXREP; ++h) sc[i][h] = -INFINITY;
+        if (c < nch) {
+            const int j = c * 64 + lane;
+            if (j < nk) {
+                float s[DA_MAXREP] = {0.0f, 0.0f, 0.0f, 0.0f};
+                // transposed cache: for every d the 64 lanes (keys) read 256 contiguous bytes; all 64 loads are issued up front
+                float kreg[64];
+                if (sd.kt_stride) {
+#pragma unroll
+                    for (int dd = 0; dd < 64; ++dd) kreg[dd] = Kb[(size_t)dd * sd.kt_stride + j];
+                } else {
+                    const __attribute__((address_space(1))) f32x4* kr = (const __attribute__((address_space(1))) f32x4*)(Kb + (size_t)j * sd.kv_stride);
+#pragma unroll
+                    for (int q4 = 0; q4 < 16; ++q4) { const f32x4 t4 = kr[q4]; kreg[4 * q4] = t4[0]; kreg[4 * q4 + 1] = t4[1]; kreg[4 * q4 + 2] = t4[2]; kreg[4 * q4 + 3] = t4[3]; }
+                }
+#pragma unroll
+                for (int q4 = 0; q4 < 16; ++q4) {
+                    const f32x4 kv = f32x4{kreg[4 * q4], kreg[4 * q4 + 1], kreg[4 * q4 + 2], kreg[4 * q4 + 3]};
+#pragma unroll
+                    for (int h = 0; h < DA_MAXREP; ++h)
+                        if (h < rep) {
+                            const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + h * 64 + q4 * 4);
+                            s[h] = cz_fma(qv[0], kv[0], s[h]); s[h] = cz_fma(qv[1], kv[1], s[h]);
+                            s[h] = cz_fma(qv[2], kv[2], s[h]); s[h] = cz_fma(qv[3], kv[3], s[h]);
+                        }
+                }
+#pragma unroll
+                for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) { sc[i][h] = s[h] * 0.125f; lm[h] = sc[i][h] > lm[h] ? sc[i][h] : lm[h]; }
             }
         }
+    }
 #pragma unroll
-        for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) S[h * s_stride + j] = j < nk ? s[h] * 0.125f : -INFINITY;
-    }
-    __syncthreads();
-    // row max
-    {
-        const int h = tid >> 7, q = tid & 127;          // 128 threads per head (rep <= 4)
-        float m = -INFINITY;
-        if (h < rep) for (int j = q; j < nkp; j += 128) { const float v = S[h * s_stride + j]; m = v > m ? v : m; }
+    for (int h = 0; h < DA_MAXREP; ++h) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const float y = __shfl_xor(m, o); m = y > m ? y : m; }
-        if (lane == 0) red[wave] = m;
+        for (int o = 32; o > 0; o >>= 1) { const float y = __shfl_xor(lm[h], o); lm[h] = y > lm[h] ? y : lm[h]; }
     }
-    __syncthreads();
-    if (tid < rep) { const float a = red[tid * 2], b = red[tid * 2 + 1]; red[16 + tid] = a > b ? a : b; }
-    __syncthreads();
-    for (int h = 0; h < rep; ++h) {
-        const float mx = red[16 + h];
-        for (int j = tid; j < nkp; j += DA_THREADS) S[h * s_stride + j] = cz_expf(S[h * s_stride + j] - mx);
-    }
-    __syncthreads();
-    // canonical sum: (head, chunk) sequential partials, chunks left to right
-    for (int i = tid; i < rep * nch; i += DA_THREADS) {
-        const int h = i / nch, c = i % nch;
-        const float* p = S + h * s_stride + c * 64;
-        float acc = 0.0f;
-#pragma unroll 8
-        for (int k = 0; k < 64; ++k) acc = acc + p[k];
-        part[h * 32 + c] = acc;
-    }
-    __syncthreads();
-    if (tid < rep) {
-        float t = part[tid * 32];
-        for (int c = 1; c < nch; ++c) t = t + part[tid * 32 + c];
-        red[24 + tid] = t;
-    }
-    __syncthreads();
-    for (int h = 0; h < rep; ++h) {
-        const float sm_ = red[24 + h];
-        for (int j = tid; j < nkp; j += DA_THREADS) S[h * s_stride + j] = S[h * s_stride + j] / sm_;
-    }
-    __syncthreads();
-    // P.V: lane = d, chunk partials (fmaf chain over keys ascending), then chunks left to right
-    for (int c = wave; c < nch; c += NWV) {
-        float acc[DA_MAXREP] = {0.0f, 0.0f, 0.0f, 0.0f};
-        const int jend = nk - c * 64 < 64 ? nk - c * 64 : 64;
-        const float* vp = Vb + (size_t)(c * 64) * sd.kv_stride + lane;
-        float vreg[64];                                   // the whole 64-key slab of this lane's column: all loads in flight at once
+    if (lane == 0) {
 #pragma unroll
-        for (int j = 0; j < 64; ++j) vreg[j] = j < jend ? vp[(size_t)j * sd.kv_stride] : 0.0f;
-        // keys past nk have p == 0 (exp(-inf)) and v == 0: fma(0, 0, acc) == acc, so the chain below needs no guard
+        for (int h = 0; h < DA_MAXREP; ++h) red[wave * DA_MAXREP + h] = lm[h];
+    }
+    __syncthreads();
+    // ---- phase 2: e = exp(s - max), chunk sums in the canonical order (one lane per head walks the 64 values)
+    float gm[DA_MAXREP];
 #pragma unroll
-        for (int j = 0; j < 64; ++j) {
+    for (int h = 0; h < DA_MAXREP; ++h) {
+        float m = red[h];
 #pragma unroll
-            for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) acc[h] = cz_fma(S[h * s_stride + c * 64 + j], vreg[j], acc[h]);
+        for (int w = 1; w < DA_WAVES; ++w) { const float y = red[w * DA_MAXREP + h]; m = y > m ? y : m; }
+        gm[h] = m;
+    }
+#pragma unroll
+    for (int i = 0; i < DA_MAXC; ++i) {
+        const int c = wave + DA_WAVES * i;
+        if (c < nch) {
+#pragma unroll
+            for (int h = 0; h < DA_MAXREP; ++h)
+                if (h < rep) { sc[i][h] = cz_expf(sc[i][h] - gm[h]); S[h * s_stride + c * 64 + lane] = sc[i][h]; }
         }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);                 // this wave's LDS writes are visible to its own lanes
 #pragma unroll
-        for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) part[(c * DA_MAXREP + h) * 64 + lane] = acc[h];
+    for (int i = 0; i < DA_MAXC; ++i) {
+        const int c = wave + DA_WAVES * i;
+        if (c < nch && lane < rep) {
+            const float* p = S + lane * s_stride + c * 64;
+            float acc = 0.0f;
+#pragma unroll 16
+            for (int k = 0; k < 64; ++k) acc = acc + p[k];
+            csum[lane * 32 + c] = acc;
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: total (chunks left to right), p = e / total, P.V chunk partials (lane = d, keys ascending)
+    float tot[DA_MAXREP];
+#pragma unroll
+    for (int h = 0; h < DA_MAXREP; ++h) {
+        float t = 0.0f;
+        if (h < rep) { t = csum[h * 32]; for (int c = 1; c < nch; ++c) t = t + csum[h * 32 + c]; }
+        tot[h] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < DA_MAXC; ++i) {
+        const int c = wave + DA_WAVES * i;
+        if (c < nch) {
+#pragma unroll
+            for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) S[h * s_stride + c * 64 + lane] = sc[i][h] / tot[h];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+    for (int i = 0; i < DA_MAXC; ++i) {
+        const int c = wave + DA_WAVES * i;
+        if (c < nch) {
+            float acc[DA_MAXREP] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const int jend = nk - c * 64 < 64 ? nk - c * 64 : 64;
+            gfloat* vp = Vb + (size_t)(c * 64) * sd.kv_stride + lane;
+            float vreg[64];                               // the whole 64-key slab of this lane's column: all loads in flight at once
+            // unconditional loads (row index clamped) + select afterwards: a per-element "load or 0" on a runtime bound makes hipcc
+            // branch around every load and wait for each one (64 serialized round trips per chunk)
+#pragma unroll
+            for (int j = 0; j < 64; ++j) { const int jj = j < jend ? j : jend - 1; vreg[j] = vp[(size_t)jj * sd.kv_stride]; }
+#pragma unroll
+            for (int j = 0; j < 64; ++j) vreg[j] = j < jend ? vreg[j] : 0.0f;
+            // keys past nk have p == 0 (exp(-inf)) and v == 0: fma(0, 0, acc) == acc, so the chain below needs no guard
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+#pragma unroll
+                for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) acc[h] = cz_fma(S[h * s_stride + c * 64 + j], vreg[j], acc[h]);
+            }
+#pragma unroll
+            for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) part[(c * DA_MAXREP + h) * 64 + lane] = acc[h];
+        }
     }
     __syncthreads();
     if (tid < rep * 64) {
@@ -395,16 +452,28 @@ __global__ __launch_bounds__(DA_THREADS) void dec_attn_kernel(const float* __res
     }
 }
 static int da_s_stride(int max_nk) { return ((max_nk + 63) / 64) * 64 + 4; }
-static size_t da_smem(int max_nk) { return (size_t)(DA_MAXREP * 64 + DA_MAXREP * da_s_stride(max_nk) + 32 * DA_MAXREP * 64 + 64) * sizeof(float); }
+static size_t da_smem(int max_nk) {
+    return (size_t)(DA_MAXREP * 64 + DA_MAXREP * da_s_stride(max_nk) + 32 * DA_MAXREP * 64 + DA_WAVES * DA_MAXREP + DA_MAXREP * 32) * sizeof(float);
+}
 hipError_t cz_dec_attn_prepare(int max_nk) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk));
+    return e;
 }
 hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nstreams, int max_nk,
                               int n_heads, int n_kv, size_t kv_off, const int* pos_dev) {
     if (nstreams <= 0) return hipSuccess;
     const int rep = n_heads / n_kv;
     if (rep < 1 || rep > DA_MAXREP || max_nk > 2048) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(dec_attn_kernel, dim3(nstreams, n_kv), dim3(DA_THREADS), da_smem(max_nk), st, Q, ldq, O, ldo, descs, n_heads, n_kv,
-                       da_s_stride(max_nk), kv_off, pos_dev);
+    const dim3 grid(nstreams, n_kv), block(DA_THREADS);
+    const size_t smem = da_smem(max_nk); const int ss = da_s_stride(max_nk);
+    switch (rep) {
+        case 1: hipLaunchKernelGGL(dec_attn_kernel<1>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev); break;
+        case 2: hipLaunchKernelGGL(dec_attn_kernel<2>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev); break;
+        case 3: hipLaunchKernelGGL(dec_attn_kernel<3>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev); break;
+        default: hipLaunchKernelGGL(dec_attn_kernel<4>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev); break;
+    }
     return hipGetLastError();
 }

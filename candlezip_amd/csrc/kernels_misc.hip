@@ -106,8 +106,13 @@ __global__ void rope_kernel(float* __restrict__ QKV, int ld, const cz_rope_desc*
             const float o1 = a - b, o2 = cc + dd;
             if (h < n_heads) { x[t] = o1; x[t + 32] = o2; }
             else {
-                float* kd = d.k_dst + (size_t)pos * d.dst_stride + (h - n_heads) * 64;
-                kd[t] = o1; kd[t + 32] = o2;
+                if (d.kt_stride) {
+                    float* kd = d.k_dst + (size_t)((h - n_heads) * 64) * d.kt_stride + pos;
+                    kd[(size_t)t * d.kt_stride] = o1; kd[(size_t)(t + 32) * d.kt_stride] = o2;
+                } else {
+                    float* kd = d.k_dst + (size_t)pos * d.dst_stride + (h - n_heads) * 64;
+                    kd[t] = o1; kd[t + 32] = o2;
+                }
             }
         } else {
             const int hv = h - n_heads - n_kv;

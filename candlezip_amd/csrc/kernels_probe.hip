@@ -172,7 +172,7 @@ extern "C" cz_status cz_debug_attention(const float* Q, const float* K, const fl
     PCHK(hipMemcpy(dK, K, (size_t)nk * nkv * 64 * 4, hipMemcpyHostToDevice));
     PCHK(hipMemcpy(dV, V, (size_t)nk * nkv * 64 * 4, hipMemcpyHostToDevice));
     PCHK(hipMemset(dO, 0xFF, (size_t)M * nh * 64 * 4));
-    hd.row0 = 0; hd.nrows = M; hd.pos0 = pos0; hd.kv_stride = nkv * 64; hd.k = dK; hd.v = dV;
+    hd.row0 = 0; hd.nrows = M; hd.pos0 = pos0; hd.kv_stride = nkv * 64; hd.k = dK; hd.v = dV; hd.kt_stride = 0; hd.pad_ = 0;
     PCHK(hipMemcpy(dd, &hd, sizeof hd, hipMemcpyHostToDevice));
     PCHK(cz_attention_prepare(2048));
     PCHK(cz_launch_attention(0, dQ, nh * 64, dO, nh * 64, dd, 1, M, nk, nh, nkv, 0, nullptr));

@@ -305,8 +305,8 @@ static cz_status ensure_streams(cz_session* s, int B) {
         std::vector<cz_seq_desc> sd(s->max_streams); std::vector<cz_rope_desc> rd(s->max_streams);
         for (int b = 0; b < s->max_streams; ++b) {
             float* kb = s->kvcache + (size_t)b * s->kv_stream_stride;
-            sd[b] = {b, 1, 0, (int)kvd, kb, kb + s->ctx_cap * kvd};
-            rd[b] = {b, 1, 0, (int)kvd, kb, kb + s->ctx_cap * kvd};
+            sd[b] = {b, 1, 0, (int)kvd, kb, kb + s->ctx_cap * kvd, (int)s->ctx_cap, 0};     // K transposed [kvd][ctx_cap], V rows [ctx_cap][kvd]
+            rd[b] = {b, 1, 0, (int)kvd, kb, kb + s->ctx_cap * kvd, (int)s->ctx_cap, 0};
         }
         HIPCHK(hipMalloc((void**)&s->step_seqd, sd.size() * sizeof(cz_seq_desc)));
         HIPCHK(hipMalloc((void**)&s->step_roped, rd.size() * sizeof(cz_rope_desc)));
@@ -369,8 +369,8 @@ static cz_status llama_reprime(cz_session* s, int B, int hl) {
     std::vector<cz_seq_desc> sd(B); std::vector<cz_rope_desc> rd(B); std::vector<int> ri(B);
     for (int b = 0; b < B; ++b) {
         float* kb = s->kvcache + (size_t)b * s->kv_stream_stride;
-        sd[b] = {b * hl, hl, 0, (int)kvd, kb, kb + s->ctx_cap * kvd};
-        rd[b] = {b * hl, hl, 0, (int)kvd, kb, kb + s->ctx_cap * kvd};
+        sd[b] = {b * hl, hl, 0, (int)kvd, kb, kb + s->ctx_cap * kvd, (int)s->ctx_cap, 0};
+        rd[b] = {b * hl, hl, 0, (int)kvd, kb, kb + s->ctx_cap * kvd, (int)s->ctx_cap, 0};
         ri[b] = b * hl + hl - 1;
     }
     CZCHK(s->seqd.ensure(sd.size() * sizeof(cz_seq_desc))); CZCHK(s->roped.ensure(rd.size() * sizeof(cz_rope_desc)));
@@ -475,8 +475,8 @@ static cz_status encode_llama(cz_session* s, size_t n_streams, const uint32_t* c
             const uint32_t* src = ids[sg.stream];
             for (size_t p = 0; p < T; ++p) tok[row + p] = src[sg.hist_start + p];
             float* kb = qkv + row * nq + d;                     // K/V stay in place inside the fused QKV rows
-            sd[q] = {(int)row, (int)T, 0, nq, kb, kb + kvd};
-            rd[q] = {(int)row, (int)T, 0, nq, kb, kb + kvd};
+            sd[q] = {(int)row, (int)T, 0, nq, kb, kb + kvd, 0, 0};
+            rd[q] = {(int)row, (int)T, 0, nq, kb, kb + kvd, 0, 0};
             for (size_t i = sg.start_i; i < sg.end_i; ++i) {
                 rowidx.push_back((int)(row + (i - sg.hist_start)));
                 sym.push_back(src[i + 1]);
