@@ -32,6 +32,14 @@ def make_streams(rank, n_streams, n_tokens, vocab):
     return [np.concatenate([[0], rng.integers(0, vocab, n_tokens)]).astype(np.uint32) for _ in range(n_streams)]
 
 
+def note(msg):
+    """progress on stderr (long runs must not look hung to the GPU harness)"""
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def self_test_step(cz, sess, streams, context, reprime):
     """compress + decompress of every stream; returns (tokens, payload_bytes, t_encode, t_decode)"""
     t0 = time.perf_counter()
@@ -46,6 +54,7 @@ def self_test_step(cz, sess, streams, context, reprime):
     for s, o in zip(streams, outs):
         if not np.array_equal(s, o):
             raise RuntimeError("self-test round trip mismatch")
+    note(f"self-test pass: {sum(s.size - 1 for s in streams)} tokens, compress {t1 - t0:.1f}s, decompress {t2 - t1:.1f}s, round trip exact")
     return sum(s.size - 1 for s in streams), sum(len(p) for p in payloads), t1 - t0, t2 - t1
 
 
@@ -54,6 +63,7 @@ def cpu_baseline(sample_tokens, context, reprime):
     511-token batched re-prime every `reprime` tokens, host softmax->CDF->coder per token.  Bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import czo
+    note("cpu baseline: oracle in the reference schedule ...")
     o = czo.SmolLmSession(czo.smollm2_135m_config(), seed=0x5EED, embed_std=0.02)
     rng = np.random.default_rng(7)
     ids = np.concatenate([[0], rng.integers(0, 49152, sample_tokens)]).astype(np.uint32)
@@ -77,6 +87,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=128, help="streams (64 KiB chunks) per GPU, decoded in lock-step")
+    ap.add_argument("--warmup-tokens", type=int, default=1100, help="tokens/stream of a warmup step")
     ap.add_argument("--profile-tokens", type=int, default=1100, help="tokens/stream of the untimed per-family profiling pass")
     ap.add_argument("--tokens", type=int, default=17408, help="tokens per stream (~ one 64 KiB enwik8 sample)")
     ap.add_argument("--context", type=int, default=512)
@@ -97,6 +108,7 @@ def main():
     cfg = cz.tiny_llama_config() if args.tiny else cz.smollm2_135m_config()
     sess = cz.Session("smollm", cfg, seed=0x5EED, embed_std=0.02, device=local, max_streams=min(256, args.streams))
     streams = make_streams(rank, args.streams, args.tokens, cfg.vocab)   # files shard across ranks: no data-path collective
+    note(f"rank {rank}/{world}: session open, {args.streams} streams x {args.tokens} tokens")
 
     def barrier():
         torch.cuda.synchronize()
@@ -104,10 +116,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # W untimed warmup steps on the real workload (decode replays hipGraphs; nothing is profiled)
+    # W untimed warmup steps: the same streams cut to `--warmup-tokens` tokens — enough to size every buffer for the full
+    # batch, build the decode hipGraph and page the code in; nothing is profiled
     sess.profile_enable(False)
+    warm = [s[: args.warmup_tokens + 1] for s in streams]
     for _ in range(args.warmup):
-        self_test_step(cz, sess, streams, args.context, args.reprime_interval)
+        self_test_step(cz, sess, warm, args.context, args.reprime_interval)
 
     # timed region: exactly K steps.  The big-M MFMA GEMM family (launched eagerly) is HIP-event timed on the library's
     # stream inside this region; the decode-step kernels run inside hipGraphs and cannot be bracketed one by one.

@@ -70,7 +70,7 @@ hipError_t cz_launch_dec_rmsnorm(hipStream_t st, const float* X, int ldx, const 
     return hipGetLastError();
 }
 
-enum { EPI_PLAIN = 0, EPI_ROPE = 1, EPI_SWIGLU = 2 };
+enum { EPI_PLAIN = 0, EPI_ROPE = 1, EPI_SWIGLU = 2, EPI_RELUSQ = 3 };
 struct dec_gemm_args {
     const float* A; int lda;             // kq layout, [M][K]
     const uint16_t* Wd;                  // kq-packed bf16 [N][K]
@@ -79,6 +79,7 @@ struct dec_gemm_args {
     const float* R;
     // NORM: A is the residual stream x in NATURAL layout; the block applies RMSNorm (weights normw, bf16) on the fly
     const uint16_t* normw; float eps;
+    const unsigned char* row_mask;       // EPI_PLAIN: rows with mask == 0 are not stored (RWKV literal symbols do not step the model)
     // EPI_ROPE
     int n_heads, n_kv;
     const cz_rope_desc* descs; size_t kv_off; const int* pos_dev; const float* cs; const float* sn;
@@ -202,7 +203,12 @@ __global__ __launch_bounds__(768) void dec_gemm_kernel(dec_gemm_args a) {
         const int row = m0 + m * 16 + r;
         if (row >= a.M) continue;
         const float t0 = tot0[m], t1 = tot1[m];
-        if (EPI == EPI_PLAIN) {
+        if (EPI == EPI_RELUSQ) {                                       // RWKV7 channel-mix key: relu(x)^2, kq layout (feeds the value projection)
+            const float z0 = t0 > 0.0f ? t0 : 0.0f, z1 = t1 > 0.0f ? t1 : 0.0f;
+            a.C[(size_t)row * a.ldc + kq_index(n0 + cc)] = z0 * z0;
+            a.C[(size_t)row * a.ldc + kq_index(n1 + cc)] = z1 * z1;
+        } else if (EPI == EPI_PLAIN) {
+            if (a.row_mask && !a.row_mask[row]) continue;
             float v0 = t0, v1 = t1;
             if (a.R) { v0 = v0 + a.R[(size_t)row * a.ldc + n0 + cc]; v1 = v1 + a.R[(size_t)row * a.ldc + n1 + cc]; }
             a.C[(size_t)row * a.ldc + n0 + cc] = v0;
@@ -271,6 +277,20 @@ hipError_t cz_launch_dec_gemm_plain(hipStream_t st, const float* A, int lda, con
     if (N % 32 || K % 64) return hipErrorInvalidValue;
     dec_gemm_args a{}; a.A = A; a.lda = lda; a.Wd = Wd; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc; a.R = R; a.normw = normw; a.eps = eps;
     return dec_gemm_launch<EPI_PLAIN>(st, a, N / 32);
+}
+hipError_t cz_launch_dec_gemm_masked(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* C, int ldc, const float* R, int M, int N, int K,
+                                     const unsigned char* row_mask) {
+    if (M <= 0) return hipSuccess;
+    if (N % 32 || K % 64) return hipErrorInvalidValue;
+    dec_gemm_args a{}; a.A = A; a.lda = lda; a.Wd = Wd; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc; a.R = R; a.row_mask = row_mask;
+    return dec_gemm_launch<EPI_PLAIN>(st, a, N / 32);
+}
+// C (kq layout, [M][N]) = relu(A(kq) . W^T)^2
+hipError_t cz_launch_dec_gemm_relusq(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* C, int ldc, int M, int N, int K) {
+    if (M <= 0) return hipSuccess;
+    if (N % 32 || K % 64) return hipErrorInvalidValue;
+    dec_gemm_args a{}; a.A = A; a.lda = lda; a.Wd = Wd; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc;
+    return dec_gemm_launch<EPI_RELUSQ>(st, a, N / 32);
 }
 // fused QKV projection + RoPE; q -> Q [M][n_heads*64] natural, k/v -> per-stream cache rows at position *pos_dev
 hipError_t cz_launch_dec_gemm_qkv(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* Q, int ldq, int M, int K, int n_heads, int n_kv,

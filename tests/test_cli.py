@@ -1,0 +1,55 @@
+"""CLI surface (src/main.rs:34-141): flag names/defaults are kept, agent flags are rejected loudly, no silent CPU path."""
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*argv):
+    return subprocess.run([sys.executable, "-m", "candlezip_amd", *argv], cwd=ROOT, capture_output=True, text=True)
+
+
+def test_defaults_match_reference_cli():
+    sys.path.insert(0, ROOT)
+    from candlezip_amd.cli import build_parser
+    a = build_parser().parse_args(["compress", "in", "out"])
+    assert (a.backend, a.context, a.reprime_interval, a.cpu, a.force_mismatch) == ("smollm", 512, 512, False, False)
+    assert a.model_repo == "HuggingFaceTB/SmolLM2-135M" and a.tokenizer_file == "tokenizer.json"
+    assert a.rwkv_model == "modeldir/prepared/model.safetensors" and a.rwkv_tokenizer == "modeldir/rwkv_vocab_v20230424.json"
+    b = build_parser().parse_args(["--backend", "rwkv7", "--context", "1024", "--reprime-interval", "1024", "self-test", "f"])
+    assert (b.backend, b.context, b.reprime_interval, b.command, b.input) == ("rwkv7", 1024, 1024, "self-test", "f")
+
+
+def test_agent_flags_and_cpu_are_rejected_not_ignored():
+    r = _run("--agent", "compress", "a", "b")
+    assert r.returncode != 0 and "not supported in this build" in r.stderr
+    r = _run("--scan-lookahead", "64", "self-test", "a")
+    assert r.returncode != 0 and "not supported" in r.stderr
+    r = _run("--cpu", "self-test", "a")
+    assert r.returncode != 0 and "no CPU path" in r.stderr
+
+
+@pytest.mark.gpu
+def test_self_test_roundtrip_rwkv7_literals_and_smollm_ids(tmp_path):
+    # rwkv7 without a vocab file: every byte is a literal symbol (src/main.rs:863-868) -> exact byte round trip
+    src = tmp_path / "sample.bin"
+    src.write_bytes(bytes(range(256)) + b"hello candlezip")
+    r = _run("--backend", "rwkv7", "--synthetic", "7", "--rwkv-tokenizer", str(tmp_path / "missing.json"), "self-test", str(src))
+    assert r.returncode == 0 and "Roundtrip OK" in r.stdout, r.stderr + r.stdout
+    assert "Bits per byte" in r.stdout and "Compression" in r.stdout
+    # smollm with token ids: compress, then decompress back to ids
+    ids = np.random.default_rng(0).integers(0, 49152, 700).astype("<u4")
+    idf = tmp_path / "tok.ids"; ids.tofile(idf)
+    inp = tmp_path / "in.txt"; inp.write_bytes(b"x" * 1000)
+    out = tmp_path / "o.canz"; back = tmp_path / "back.ids"
+    r = _run("--synthetic", "1", "--token-ids", str(idf), "compress", str(inp), str(out))
+    assert r.returncode == 0 and "bits/byte=" in r.stdout, r.stderr
+    r = _run("--synthetic", "1", "--token-ids", str(idf), "decompress", str(out), str(back))
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.fromfile(back, "<u4"), ids)
+    # a different model must be refused unless --force-mismatch (src/main.rs:2450-2459)
+    r = _run("--synthetic", "2", "--token-ids", str(idf), "decompress", str(out), str(back))
+    assert r.returncode != 0 and "model hash mismatch" in r.stderr

@@ -147,3 +147,63 @@ def test_decode_paths_agree_graph_eager_v1(cz, czo, tiny_pair):
         for s, out in zip(streams, outs):
             assert np.array_equal(s, out), knobs
     assert g.debug_get("cdf_fallback_rows") == 0
+
+
+# ---------------------------------------------------------------- RWKV7 (config 4: recurrent-state kernel path)
+@pytest.fixture(scope="module")
+def rwkv_pair(cz, czo):
+    g = cz.Session("rwkv7", cz.tiny_rwkv7_config(), seed=9, embed_std=0.05, max_streams=8)
+    o = czo.Rwkv7Session(czo.tiny_rwkv7_config(), seed=9, embed_std=0.05)
+    yield g, o
+    g.close(); o.close()
+
+
+def test_rwkv7_step_logits_bitexact(cz, czo, rwkv_pair):
+    g, o = rwkv_pair
+    assert g.vocab_size() == 512 and g.max_context_length() > 1 << 60          # usize::MAX (src/models.rs:149)
+    rng = np.random.default_rng(0)
+    toks = rng.integers(0, 512, 40).astype(np.uint32)
+    o.reset()
+    _eq(g.reprime_with_history_and_get_last_logits_tensor(toks[:1]), o.step_logits(toks[0]), "rwkv step 0")
+    for i, t in enumerate(toks[1:]):
+        _eq(g.step_logits_tensor(t), o.step_logits(t), f"rwkv step {i + 1}")
+    # reprime = reset + sequential feed (src/models.rs:161-170)
+    o.reset()
+    ref = [o.step_logits(t) for t in toks[:9]][-1]
+    _eq(g.reprime_with_history_and_get_last_logits_tensor(toks[:9]), ref, "rwkv reprime(9)")
+
+
+def test_rwkv7_encode_decode_bitexact_with_literals(cz, czo, rwkv_pair):
+    g, o = rwkv_pair
+    rng = np.random.default_rng(1)
+    streams = [np.concatenate([[0], rng.integers(0, 512, n)]).astype(np.uint32) for n in (120, 40, 75)]
+    streams[1][5] = 512 + 65; streams[1][9] = 512 + 255                        # literal escapes: coded, but do not step the model
+    pairs = g.encode_tokens_batch(streams)
+    pays = []
+    for s, (lo, hi) in zip(streams, pairs):
+        ref_p, clo, chi, zw = o.encode_tokens(s)
+        assert np.array_equal(lo, clo) and np.array_equal(hi, chi)
+        p, zw2 = cz.ac_encode_pairs(lo, hi)
+        assert p == ref_p and zw2 == zw == 0
+        pays.append(p)
+    outs = g.decode_tokens_batch(pays, [s.size - 1 for s in streams])
+    for s, out in zip(streams, outs):
+        assert np.array_equal(out, s)
+
+
+def test_rwkv7_0b1_shape_bitexact(cz, czo):
+    """RWKV7-0.1B shape (C 768, 12 layers, 12 heads x 64, ffn 3072, vocab 65536), synthetic weights"""
+    g = cz.Session("rwkv7", cz.rwkv7_0b1_config(), seed=3, embed_std=0.02, max_streams=2)
+    o = czo.Rwkv7Session(czo.rwkv7_0b1_config(), seed=3, embed_std=0.02)
+    rng = np.random.default_rng(2)
+    toks = rng.integers(0, 65536, 6).astype(np.uint32)
+    o.reset()
+    _eq(g.reprime_with_history_and_get_last_logits_tensor(toks[:1]), o.step_logits(toks[0]), "0.1B step 0")
+    for i, t in enumerate(toks[1:]):
+        _eq(g.step_logits_tensor(t), o.step_logits(t), f"0.1B step {i + 1}")
+    ids = np.concatenate([[0], toks[:4]]).astype(np.uint32)
+    ref_p, clo, chi, _ = o.encode_tokens(ids)
+    lo, hi = g.encode_tokens(ids)
+    assert np.array_equal(lo, clo) and np.array_equal(hi, chi)
+    assert np.array_equal(g.decode_tokens(ref_p, 4), ids)
+    g.close(); o.close()
