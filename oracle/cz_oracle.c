@@ -25,6 +25,13 @@ int czo_num_threads(void) {
 #endif
 }
 void czo_free(void* p) { free(p); }
+void czo_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 /* ======================================================================================
  * Scalar numerics

@@ -164,6 +164,7 @@ void czo_attention_ref(const float* Q, const float* K, const float* V, float* O,
 void czo_swiglu(const float* GU, float* H, int M, int f);
 
 int czo_num_threads(void);
+void czo_set_num_threads(int n);   /* the OpenMP runtime may already be initialised by the host process (torch): env vars are then too late */
 
 #ifdef __cplusplus
 }

@@ -66,18 +66,22 @@ def _limit_threads():
             n = min(n, max(1, int(int(q) / int(p))))
     except (OSError, ValueError):
         pass
-    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(n, 16))))
+    n = max(1, min(n, 16))
+    os.environ.setdefault("OMP_NUM_THREADS", str(n))
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     os.environ.setdefault("OMP_PROC_BIND", "false")
+    return int(os.environ.get("CZO_THREADS", n))
 
 
 def lib():
     global _lib
     if _lib is not None:
         return _lib
-    _limit_threads()
+    nthreads = _limit_threads()
     build()
     L = C.CDLL(_SO)
+    L.czo_set_num_threads.argtypes = [C.c_int]
+    L.czo_set_num_threads(nthreads)        # libgomp may have been initialised earlier by torch: the env vars are then too late
     vp, sz, u32, u64, f32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_float
     sig = {
         "czo_expf": (f32, [f32]), "czo_logf": (f32, [f32]), "czo_tanhf": (f32, [f32]),
