@@ -130,8 +130,15 @@ __global__ __launch_bounds__(768) void dec_gemm_kernel(dec_gemm_args a) {
         __syncthreads();
     }
     float tot0[MT], tot1[MT];                    // element (r = tid >> 4, c = tid & 15) of both column tiles of row tile m; threads 0..255
+    float res0[MT], res1[MT];                    // residual, fetched now so that its latency hides under the weight loads + MFMA chain
 #pragma unroll
-    for (int m = 0; m < MT; ++m) { tot0[m] = 0.0f; tot1[m] = 0.0f; }
+    for (int m = 0; m < MT; ++m) {
+        tot0[m] = 0.0f; tot1[m] = 0.0f; res0[m] = 0.0f; res1[m] = 0.0f;
+        if (EPI == EPI_PLAIN && a.R && tid < 256) {
+            const int row = m0 + m * 16 + (tid >> 4);
+            if (row < a.M) { res0[m] = a.R[(size_t)row * a.ldc + n0 + (tid & 15)]; res1[m] = a.R[(size_t)row * a.ldc + n1 + (tid & 15)]; }
+        }
+    }
     for (int c0 = 0; c0 < nch; c0 += NW) {
         const int c = c0 + wave;
         f32x4 acc0[MT], acc1[MT];
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(768) void dec_gemm_kernel(dec_gemm_args a) {
         } else if (EPI == EPI_PLAIN) {
             if (a.row_mask && !a.row_mask[row]) continue;
             float v0 = t0, v1 = t1;
-            if (a.R) { v0 = v0 + a.R[(size_t)row * a.ldc + n0 + cc]; v1 = v1 + a.R[(size_t)row * a.ldc + n1 + cc]; }
+            if (a.R) { v0 = v0 + res0[m]; v1 = v1 + res1[m]; }
             a.C[(size_t)row * a.ldc + n0 + cc] = v0;
             a.C[(size_t)row * a.ldc + n1 + cc] = v1;
         } else if (EPI == EPI_SWIGLU) {
