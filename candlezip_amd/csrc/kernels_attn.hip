@@ -161,6 +161,208 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// attention_v2_kernel<REP, NI>: same arithmetic, scores kept in REGISTERS.
+// Block = (sequence, kv head, tile of 16 query rows); the REP query heads of the kv group are REP MFMA row tiles that
+// share every staged K/V tile.  4 waves: in the QK^T phase wave w owns key tile w of every 64-key chunk and keeps its
+// REP x 16x16 score tiles in registers for all NI chunks (NI*REP*4 VGPRs, one wave per SIMD); in the P.V phase wave w owns
+// output columns 16w..16w+15 for every chunk in order.  LDS holds only one K/V tile and one e/p tile (35 KB).
+// QK^T is computed once; exact two-sweep softmax (max, then e and canonical row sums, then p = e/sum).
+#define V2_KS 68
+#define V2_VS 80
+template <int REP, int NI>
+__global__ __launch_bounds__(256, 1) void attention_v2_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
+                                                              const cz_seq_desc* __restrict__ descs, size_t kv_off, const int* __restrict__ pos_dev) {
+    __shared__ __attribute__((aligned(16))) float stage[64 * V2_VS];      // K tile (stride 68) or V tile (stride 80)
+    __shared__ __attribute__((aligned(16))) float Et[REP * 16 * V2_KS];   // e / p tile of the current chunk, [slot][key]
+    __shared__ float csum[REP * 16][NI + 1];
+    __shared__ float wred[4][REP * 16];
+    __shared__ float rsum[REP * 16];
+    cz_seq_desc sd = descs[blockIdx.z];
+    if (pos_dev) sd.pos0 = *pos_dev;
+    sd.k += kv_off; sd.v += kv_off;
+    const int tile = blockIdx.x, kvh = blockIdx.y;
+    if (tile * 16 >= sd.nrows) return;
+    const int rows_here = sd.nrows - tile * 16 < 16 ? sd.nrows - tile * 16 : 16;
+    const int nk_blk = sd.pos0 + tile * 16 + rows_here;
+    const int nch = (nk_blk + 63) / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int row_base = sd.row0 + tile * 16;
+    // A operand of QK^T: lane (i = li, g = lg) holds Q[row i][head][d = 4t + g]
+    float qreg[REP][16];
+#pragma unroll
+    for (int rt = 0; rt < REP; ++rt) {
+        const bool valid = li < rows_here;
+        const float* qp = Q + (size_t)(row_base + (valid ? li : 0)) * ldq + (kvh * REP + rt) * 64 + lg;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { const float v = qp[4 * t]; qreg[rt][t] = valid ? v : 0.0f; }
+    }
+    f32x4 S[NI][REP];
+    // ---- phase 1: scores
+#pragma unroll
+    for (int c = 0; c < NI; ++c) {
+#pragma unroll
+        for (int rt = 0; rt < REP; ++rt) S[c][rt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (c < nch) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int key = (tid >> 4) + 16 * p, q4 = tid & 15;
+                const int j = c * 64 + key;
+                const int jj = j < nk_blk ? j : nk_blk - 1;               // clamp (never a conditional load), zero afterwards
+                f32x4 v;
+                if (sd.kt_stride) {
+                    const float* kp = sd.k + (size_t)(kvh * 64 + q4 * 4) * sd.kt_stride + jj;
+                    v = f32x4{kp[0], kp[sd.kt_stride], kp[2 * (size_t)sd.kt_stride], kp[3 * (size_t)sd.kt_stride]};
+                } else v = *reinterpret_cast<const f32x4*>(sd.k + (size_t)jj * sd.kv_stride + kvh * 64 + q4 * 4);
+                if (j >= nk_blk) v = f32x4{0, 0, 0, 0};
+                *reinterpret_cast<f32x4*>(stage + key * V2_KS + q4 * 4) = v;
+            }
+            __syncthreads();
+            float kb[16];
+            const float* kbp = stage + (wave * 16 + li) * V2_KS + lg;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) kb[t] = kbp[4 * t];
+            const int key = c * 64 + wave * 16 + li;
+#pragma unroll
+            for (int rt = 0; rt < REP; ++rt) {
+                f32x4 acc = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qreg[rt][t], kb[t], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                               // C/D: col = li -> key ; row = 4*lg + r -> query row
+                    const int qr = 4 * lg + r;
+                    float v = acc[r] * 0.125f;
+                    if (qr >= rows_here || key > sd.pos0 + tile * 16 + qr) v = -INFINITY;
+                    S[c][rt][r] = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- phase 2: row max (exact in any order)
+    float gmax[REP][4];
+#pragma unroll
+    for (int rt = 0; rt < REP; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < NI; ++c) m = S[c][rt][r] > m ? S[c][rt][r] : m;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { const float y = __shfl_xor(m, o); m = y > m ? y : m; }
+            if (li == 0) wred[wave][rt * 16 + 4 * lg + r] = m;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < REP; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = rt * 16 + 4 * lg + r;
+            float m = wred[0][s];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) m = wred[w][s] > m ? wred[w][s] : m;
+            gmax[rt][r] = m;
+        }
+    // ---- phase 3: e = exp(s - max); canonical row sums (sequential inside a 64-key chunk, chunks left to right)
+#pragma unroll
+    for (int c = 0; c < NI; ++c) {
+        if (c < nch) {
+#pragma unroll
+            for (int rt = 0; rt < REP; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qr = 4 * lg + r;
+                    const float e = qr < rows_here ? cz_expf(S[c][rt][r] - gmax[rt][r]) : 0.0f;
+                    S[c][rt][r] = e;
+                    Et[(rt * 16 + qr) * V2_KS + wave * 16 + li] = e;
+                }
+            __syncthreads();
+            if (tid < REP * 16) {
+                const float* p = Et + tid * V2_KS;
+                float acc = 0.0f;
+#pragma unroll 16
+                for (int k = 0; k < 64; ++k) acc = acc + p[k];
+                csum[tid][c] = acc;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < REP * 16) {
+        float t = csum[tid][0];
+        for (int c = 1; c < nch; ++c) t = t + csum[tid][c];
+        rsum[tid] = t;
+    }
+    __syncthreads();
+    float rs[REP][4];
+#pragma unroll
+    for (int rt = 0; rt < REP; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rs[rt][r] = rsum[rt * 16 + 4 * lg + r];
+    // ---- phase 4: p = e / sum ; out = P.V (wave w -> output columns 16w.., chunks in order)
+    f32x4 tot[REP];
+#pragma unroll
+    for (int rt = 0; rt < REP; ++rt) tot[rt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < NI; ++c) {
+        if (c < nch) {
+#pragma unroll
+            for (int rt = 0; rt < REP; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qr = 4 * lg + r;
+                    Et[(rt * 16 + qr) * V2_KS + wave * 16 + li] = qr < rows_here ? S[c][rt][r] / rs[rt][r] : 0.0f;
+                }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int key = (tid >> 4) + 16 * p, q4 = tid & 15;
+                const int j = c * 64 + key;
+                const int jj = j < nk_blk ? j : nk_blk - 1;
+                f32x4 v = *reinterpret_cast<const f32x4*>(sd.v + (size_t)jj * sd.kv_stride + kvh * 64 + q4 * 4);
+                if (j >= nk_blk) v = f32x4{0, 0, 0, 0};
+                *reinterpret_cast<f32x4*>(stage + key * V2_VS + q4 * 4) = v;
+            }
+            __syncthreads();
+            float vb[16];
+            const float* vbp = stage + lg * V2_VS + wave * 16 + li;          // B[k = 4t + lg][j = li] = V[key][col]
+#pragma unroll
+            for (int t = 0; t < 16; ++t) vb[t] = vbp[4 * t * V2_VS];
+#pragma unroll
+            for (int rt = 0; rt < REP; ++rt) {
+                const float* pa = Et + (rt * 16 + li) * V2_KS + lg;          // A[i = li][k = 4t + lg] = P[row][key]
+                f32x4 acc = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * t], vb[t], acc, 0, 0, 0);
+                if (c == 0) tot[rt] = acc;
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tot[rt][r] = tot[rt][r] + acc[r];
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < REP; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qr = 4 * lg + r;
+            if (qr < rows_here) O[(size_t)(row_base + qr) * ldo + (kvh * REP + rt) * 64 + wave * 16 + li] = tot[rt][r];
+        }
+}
+template <int REP>
+static hipError_t launch_v2(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nseq, int max_rows, int max_nk,
+                            int n_kv, size_t kv_off, const int* pos_dev) {
+    const dim3 grid((max_rows + 15) / 16, n_kv, nseq), block(256);
+    const int ni = (max_nk + 63) / 64;
+    if (ni <= 8) hipLaunchKernelGGL((attention_v2_kernel<REP, 8>), grid, block, 0, st, Q, ldq, O, ldo, descs, kv_off, pos_dev);
+    else if (ni <= 16) hipLaunchKernelGGL((attention_v2_kernel<REP, 16>), grid, block, 0, st, Q, ldq, O, ldo, descs, kv_off, pos_dev);
+    else if (ni <= 24) hipLaunchKernelGGL((attention_v2_kernel<REP, 24>), grid, block, 0, st, Q, ldq, O, ldo, descs, kv_off, pos_dev);
+    else hipLaunchKernelGGL((attention_v2_kernel<REP, 32>), grid, block, 0, st, Q, ldq, O, ldo, descs, kv_off, pos_dev);
+    return hipGetLastError();
+}
+
+int g_attn_v1 = 0;     // test knob: 1 = the LDS-resident v1 kernel
 static int s_stride_for(int max_nk) { return ((max_nk + 63) / 64) * 64 + 4; }
 size_t cz_attention_smem_bytes(int max_nk) { return (size_t)(16 * s_stride_for(max_nk) + 64 * VS + 16 * 32 + 16) * sizeof(float); }
 hipError_t cz_attention_prepare(int max_nk) {
@@ -172,6 +374,17 @@ hipError_t cz_launch_attention(hipStream_t st, const float* Q, int ldq, float* O
     if (nseq <= 0 || max_rows <= 0) return hipSuccess;
     const int rep = n_heads / n_kv;
     if (rep < 1 || rep > 16 || n_heads % n_kv) return hipErrorInvalidValue;
+    // v2 keeps NI*REP score tiles in registers: beyond these shapes the compiler spills them, so v1 (LDS-resident) takes over
+    const int ni_ = (max_nk + 63) / 64;
+    const bool v2_fits = (rep <= 2 && ni_ <= 32) || (rep == 3 && ni_ <= 24) || (rep == 4 && ni_ <= 16);
+    if (!g_attn_v1 && v2_fits && max_rows > 1) {
+        switch (rep) {
+            case 1: return launch_v2<1>(st, Q, ldq, O, ldo, descs, nseq, max_rows, max_nk, n_kv, kv_off, pos_dev);
+            case 2: return launch_v2<2>(st, Q, ldq, O, ldo, descs, nseq, max_rows, max_nk, n_kv, kv_off, pos_dev);
+            case 3: return launch_v2<3>(st, Q, ldq, O, ldo, descs, nseq, max_rows, max_nk, n_kv, kv_off, pos_dev);
+            default: return launch_v2<4>(st, Q, ldq, O, ldo, descs, nseq, max_rows, max_nk, n_kv, kv_off, pos_dev);
+        }
+    }
     const int RT = 16 / rep;
     const int ss = s_stride_for(max_nk);
     dim3 grid((max_rows + RT - 1) / RT, n_kv, nseq);

@@ -19,6 +19,7 @@
 #include "cz_kernels.h"
 #include "cz_session.h"
 
+extern int g_attn_v1;
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t _e = (expr);                                                                        \
@@ -740,6 +741,7 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "serial_cdf")) s->serial_cdf = (int)value;
     else if (!strcmp(key, "decode_v1")) s->decode_v1 = (int)value;
     else if (!strcmp(key, "no_graph")) s->no_graph = (int)value;
+    else if (!strcmp(key, "attn_v1")) g_attn_v1 = (int)value;
     else { cz_set_error("unknown debug key %s", key); return CZ_ERR_ARG; }
     return CZ_OK;
 }

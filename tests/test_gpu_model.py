@@ -138,7 +138,7 @@ def test_decode_paths_agree_graph_eager_v1(cz, czo, tiny_pair):
     for s in streams:
         lo, hi = g.encode_tokens(s)
         pays.append(cz.ac_encode_pairs(lo, hi)[0])
-    for knobs in ({}, {"no_graph": 1}, {"decode_v1": 1}, {"serial_cdf": 1}):
+    for knobs in ({}, {"no_graph": 1}, {"decode_v1": 1}, {"serial_cdf": 1}, {"attn_v1": 1}):
         for k, v in knobs.items():
             g.debug_set(k, v)
         outs = g.decode_tokens_batch(pays, [s.size - 1 for s in streams])
