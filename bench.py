@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=128, help="streams (64 KiB chunks) per GPU, decoded in lock-step")
+    ap.add_argument("--lanes", type=int, default=4, help="concurrent lock-step decode groups per GPU (library decode lanes)")
+    ap.add_argument("--lane-streams", type=int, default=128, help="streams per lock-step group")
     ap.add_argument("--warmup-tokens", type=int, default=1100, help="tokens/stream of a warmup step")
     ap.add_argument("--profile-tokens", type=int, default=1100, help="tokens/stream of the untimed per-family profiling pass")
     ap.add_argument("--tokens", type=int, default=17408, help="tokens per stream (~ one 64 KiB enwik8 sample)")
@@ -106,7 +108,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     import candlezip_amd as cz
     cfg = cz.tiny_llama_config() if args.tiny else cz.smollm2_135m_config()
-    sess = cz.Session("smollm", cfg, seed=0x5EED, embed_std=0.02, device=local, max_streams=min(256, args.streams))
+    sess = cz.Session("smollm", cfg, seed=0x5EED, embed_std=0.02, device=local, max_streams=min(256, args.streams, args.lane_streams))
+    sess.debug_set("max_lanes", args.lanes)
     streams = make_streams(rank, args.streams, args.tokens, cfg.vocab)   # files shard across ranks: no data-path collective
     note(f"rank {rank}/{world}: session open, {args.streams} streams x {args.tokens} tokens")
 
@@ -177,7 +180,8 @@ def main():
             "config": {"workload": f"enwik8 64 KiB samples, chunk-sharded: {args.streams} streams x {args.tokens} tokens per GPU, "
                                    f"SmolLM2-135M shape ({'tiny test model' if args.tiny else 'd576 L30 9q/3kv ffn1536 V49152'}), "
                                    f"context {args.context}, reprime_interval {args.reprime_interval}, seeded synthetic weights",
-                       "streams_per_gpu": args.streams, "tokens_per_stream": args.tokens, "parallelism": f"files x{world} (no data-path collective)"},
+                       "streams_per_gpu": args.streams, "decode_lanes": min(args.lanes, -(-args.streams // min(256, args.streams, args.lane_streams))),
+                       "streams_per_lane": min(256, args.streams, args.lane_streams), "tokens_per_stream": args.tokens, "parallelism": f"files x{world} (no data-path collective)"},
             "bits_per_byte": None,
             "bits_per_token_synthetic": round(8.0 * byt / max(tok, 1), 3),
             "compress_tokens_per_s_rank0": round(tok / te, 1) if te else None,

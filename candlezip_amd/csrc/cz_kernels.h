@@ -39,7 +39,9 @@ hipError_t cz_attention_prepare(int max_nk);
 // logits -> coder interval of `sym` (encode) ; mode 0 = smollm (softmax_pdf), 1 = rwkv7 (floor + 256 literals)
 // (exact-parallel kernel when supported, else the serial walk; fallback_count (optional, device) counts rows that fell back)
 hipError_t cz_launch_cdf_pairs(hipStream_t st, const float* logits, int ld, const uint32_t* sym, uint32_t* c_lo, uint32_t* c_hi,
-                               int rows, int vocab, int mode, unsigned* fallback_count);
+                               int rows, int vocab, int mode, unsigned* fallback_count, double* scratch);
+#define CZ_CDF_PAR_MAX_GRID 1024
+size_t cz_cdf_par_scratch_bytes(int vocab);     // the `scratch` the exact-parallel CDF launchers need (owned by the session)
 hipError_t cz_launch_cdf_pairs_serial(hipStream_t st, const float* logits, int ld, const uint32_t* sym, uint32_t* c_lo, uint32_t* c_hi,
                                       int rows, int vocab, int mode);
 bool cz_cdf_par_supported(int vocab, int mode);
@@ -55,8 +57,8 @@ struct cz_dec_state {
 };
 hipError_t cz_launch_dec_init(hipStream_t st, cz_dec_state* st_arr, int nstreams);
 hipError_t cz_launch_decode_symbol(hipStream_t st, const float* logits, int ld, cz_dec_state* st_arr, uint32_t* sym_out, int nstreams,
-                                   int vocab, int mode, unsigned long long i, unsigned* fallback_count, const unsigned long long* step_dev);
-hipError_t cz_cdf_par_prepare(int vocab);
+                                   int vocab, int mode, unsigned long long i, unsigned* fallback_count, const unsigned long long* step_dev,
+                                   double* scratch);
 hipError_t cz_launch_decode_symbol_serial(hipStream_t st, const float* logits, int ld, cz_dec_state* st_arr, uint32_t* sym_out, int nstreams,
                                           int vocab, int mode, unsigned long long i, const unsigned long long* step_dev);
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <vector>
+#include <string>
 #include "../../include/candlezip.h"
 #include "cz_kernels.h"
 
@@ -9,6 +10,7 @@
 
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
+    unsigned long long* gen = nullptr;   // bumped when the buffer moves (captured graphs hold raw pointers)
     cz_status ensure(size_t bytes);
     void release();
 };
@@ -43,7 +45,15 @@ struct cz_session {
     size_t max_batch_rows = 98304, logit_batch_rows = 8192;
     int force_big_gemm = 0, serial_cdf = 0, decode_v1 = 0, no_graph = 0;
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; int graph_B = 0; unsigned long long graph_gen = 0;
+    unsigned long long devbuf_gen = 0;
     unsigned* fallback_dev = nullptr;   // rows the exact-parallel CDF kernel handed to the serial walk
+    double* cdf_scratch = nullptr;      // spill rows of the exact-parallel CDF kernel (cz_cdf_par_scratch_bytes)
+    // decode lanes: independent lock-step groups replayed concurrently on their own HIP streams (share the weights)
+    std::vector<cz_session*> lanes; bool is_lane = false; int max_lanes = 4;
+    cz_session() {
+        DevBuf* all[] = {&tok, &x, &xn, &qkv, &gu, &h, &seqd, &roped, &rowidx, &sym, &clo, &chi, &xl, &logits, &payload, &outids, &decst};
+        for (DevBuf* b : all) b->gen = &devbuf_gen;
+    }
     // lock-step streams
     int max_streams = 64;
     size_t ctx_cap = 0, kv_layer_stride = 0, kv_stream_stride = 0;

@@ -343,36 +343,27 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
     }
 }
 
-static double* g_scratch = nullptr; static size_t g_scratch_bytes = 0;
-static hipError_t ensure_scratch(size_t bytes) {
-    if (bytes <= g_scratch_bytes) return hipSuccess;
-    if (g_scratch) { hipError_t e = hipFree(g_scratch); (void)e; g_scratch = nullptr; g_scratch_bytes = 0; }
-    hipError_t e = hipMalloc((void**)&g_scratch, bytes);
-    if (e == hipSuccess) g_scratch_bytes = bytes;
-    return e;
-}
 bool cz_cdf_par_supported(int vocab, int mode) { return mode == 0 && vocab <= T_PAR * LMAX; }
 
 hipError_t cz_launch_cdf_pairs(hipStream_t st, const float* logits, int ld, const uint32_t* sym, uint32_t* c_lo, uint32_t* c_hi,
-                               int rows, int vocab, int mode, unsigned* fallback_count) {
+                               int rows, int vocab, int mode, unsigned* fallback_count, double* g_scratch) {
     if (rows <= 0) return hipSuccess;
     if (!cz_cdf_par_supported(vocab, mode)) return cz_launch_cdf_pairs_serial(st, logits, ld, sym, c_lo, c_hi, rows, vocab, mode);
-    const int grid = rows < 1024 ? rows : 1024;
-    hipError_t e = ensure_scratch((size_t)1024 * vocab * sizeof(double));
-    if (e != hipSuccess) return e;
+    if (!g_scratch) return hipErrorInvalidValue;
+    const int grid = rows < CZ_CDF_PAR_MAX_GRID ? rows : CZ_CDF_PAR_MAX_GRID;
     hipLaunchKernelGGL(cdf_par_kernel<0>, dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, c_lo, c_hi, g_scratch, nullptr, nullptr, 0ull,
                        fallback_count, nullptr);
     return hipGetLastError();
 }
 hipError_t cz_launch_decode_symbol(hipStream_t st, const float* logits, int ld, cz_dec_state* st_arr, uint32_t* sym_out, int nstreams,
-                                   int vocab, int mode, unsigned long long i, unsigned* fallback_count, const unsigned long long* step_dev) {
+                                   int vocab, int mode, unsigned long long i, unsigned* fallback_count, const unsigned long long* step_dev,
+                                   double* g_scratch) {
     if (nstreams <= 0) return hipSuccess;
     if (!cz_cdf_par_supported(vocab, mode)) return cz_launch_decode_symbol_serial(st, logits, ld, st_arr, sym_out, nstreams, vocab, mode, i, step_dev);
-    hipError_t e = ensure_scratch((size_t)1024 * vocab * sizeof(double));
-    if (e != hipSuccess) return e;
+    if (!g_scratch || nstreams > CZ_CDF_PAR_MAX_GRID) return hipErrorInvalidValue;
     hipLaunchKernelGGL(cdf_par_kernel<1>, dim3(nstreams), dim3(T_PAR), 0, st, logits, ld, nstreams, vocab, nullptr, nullptr, nullptr, g_scratch, st_arr,
                        sym_out, i, fallback_count, step_dev);
     return hipGetLastError();
 }
-// allocate the scratch up front (graph capture forbids hipMalloc inside the captured region)
-hipError_t cz_cdf_par_prepare(int vocab) { return ensure_scratch((size_t)1024 * vocab * sizeof(double)); }
+// per-session scratch (one spill row per resident block; only touched when a row exhausts the LDS pool)
+size_t cz_cdf_par_scratch_bytes(int vocab) { return (size_t)CZ_CDF_PAR_MAX_GRID * vocab * sizeof(double); }

@@ -112,7 +112,8 @@ extern "C" cz_status cz_debug_cdf_pairs(const float* logits, const uint32_t* sym
     DevMem m;
     float* dl = (float*)m.alloc((size_t)rows * V * 4);
     uint32_t *ds = (uint32_t*)m.alloc(rows * 4), *dlo = (uint32_t*)m.alloc(rows * 4), *dhi = (uint32_t*)m.alloc(rows * 4);
-    if (!dl || !ds || !dlo || !dhi) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
+    double* dscr = (!serial && cz_cdf_par_supported(V, mode)) ? (double*)m.alloc((size_t)(rows < CZ_CDF_PAR_MAX_GRID ? rows : CZ_CDF_PAR_MAX_GRID) * V * 8) : nullptr;
+    if (!dl || !ds || !dlo || !dhi || (!serial && cz_cdf_par_supported(V, mode) && !dscr)) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
     PCHK(hipMemcpy(dl, logits, (size_t)rows * V * 4, hipMemcpyHostToDevice));
     PCHK(hipMemcpy(ds, sym, rows * 4, hipMemcpyHostToDevice));
     {
@@ -120,7 +121,7 @@ extern "C" cz_status cz_debug_cdf_pairs(const float* logits, const uint32_t* sym
         if (!dfb) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
         PCHK(hipMemset(dfb, 0, 64));
         if (serial) PCHK(cz_launch_cdf_pairs_serial(0, dl, V, ds, dlo, dhi, rows, V, mode));
-        else PCHK(cz_launch_cdf_pairs(0, dl, V, ds, dlo, dhi, rows, V, mode, dfb));
+        else PCHK(cz_launch_cdf_pairs(0, dl, V, ds, dlo, dhi, rows, V, mode, dfb, dscr));
         PCHK(hipDeviceSynchronize());
         if (fallbacks) PCHK(hipMemcpy(fallbacks, dfb, 4, hipMemcpyDeviceToHost));
     }
@@ -141,7 +142,8 @@ extern "C" cz_status cz_debug_decode_symbols(const float* logits, int steps, int
     uint32_t* dsym = (uint32_t*)m.alloc(64);
     cz_dec_state* dst = (cz_dec_state*)m.alloc(sizeof(cz_dec_state));
     cz_dec_state hs;
-    if (!dl || !dp || !dout || !dsym || !dst) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
+    double* dscr = (!serial && cz_cdf_par_supported(V, mode)) ? (double*)m.alloc((size_t)V * 8) : nullptr;
+    if (!dl || !dp || !dout || !dsym || !dst || (!serial && cz_cdf_par_supported(V, mode) && !dscr)) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
     PCHK(hipMemcpy(dl, logits, (size_t)steps * V * 4, hipMemcpyHostToDevice));
     if (len) PCHK(hipMemcpy(dp, payload, len, hipMemcpyHostToDevice));
     memset(&hs, 0, sizeof hs);
@@ -150,7 +152,7 @@ extern "C" cz_status cz_debug_decode_symbols(const float* logits, int steps, int
     PCHK(cz_launch_dec_init(0, dst, 1));
     for (int i = 0; i < steps; ++i) {
         if (serial) PCHK(cz_launch_decode_symbol_serial(0, dl + (size_t)i * V, V, dst, dsym, 1, V, mode, (unsigned long long)i, nullptr));
-        else PCHK(cz_launch_decode_symbol(0, dl + (size_t)i * V, V, dst, dsym, 1, V, mode, (unsigned long long)i, nullptr, nullptr));
+        else PCHK(cz_launch_decode_symbol(0, dl + (size_t)i * V, V, dst, dsym, 1, V, mode, (unsigned long long)i, nullptr, nullptr, dscr));
     }
     PCHK(hipDeviceSynchronize());
     PCHK(hipMemcpy(out_syms, dout + 1, (size_t)steps * 4, hipMemcpyDeviceToHost));

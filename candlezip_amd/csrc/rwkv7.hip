@@ -3,8 +3,8 @@
 // Replaces Rwkv7Session (src/models.rs:124-180) and candle_rwkv7 Model::forward for x[1,1]
 // (candle_rwkv7/src/models/rwkv7.rs: Model 509-524, Block 468-478, SelfAttention t==1 179-328, FeedForward 412-430,
 // group_norm 529-542) plus the RWKV branch of the token loops (src/main.rs:1824, 1916, 2302-2325, 2346-2349, 2812-2834).
-// Numerics: canonical chunk-64 fmaf reductions, owned exp/log/tanh, candle's fused layer_norm / sigmoid forms — bit-identical
-// to oracle/cz_oracle_rwkv7.c.  RWKV has no re-prime: encode and decode both walk the recurrence token by token, so the
+// Numerics: canonical chunk-64 fmaf reductions, owned exp/log/tanh, candle's fused layer_norm / sigmoid forms — the parity tests check every
+// result bit for bit against the CPU oracle.  RWKV has no re-prime: encode and decode both walk the recurrence token by token, so the
 // throughput lever is the number of streams stepped together (rows of the skinny MFMA GEMMs, kernels_decode.hip).
 //
 // Per layer and step: prep (LayerNorm + token-shift mixes, 1 block/stream) -> 7 projections -> LoRA activations -> 4
@@ -480,7 +480,7 @@ cz_status cz_rwkv7_encode(cz_session* s, size_t n_streams, const uint32_t* const
                                (const unsigned long long*)s->roped.p, (unsigned long long)i, V, m->tok, m->sym, m->mask, B);
             CZCHK(rw_step(s, B));
             s->prof_begin(PK_CDF);
-            HIPCHK(cz_launch_cdf_pairs(s->stream, m->logits, c.vocab, m->sym, (uint32_t*)s->clo.p + i * B, (uint32_t*)s->chi.p + i * B, B, c.vocab, 1, s->fallback_dev));
+            HIPCHK(cz_launch_cdf_pairs(s->stream, m->logits, c.vocab, m->sym, (uint32_t*)s->clo.p + i * B, (uint32_t*)s->chi.p + i * B, B, c.vocab, 1, s->fallback_dev, s->cdf_scratch));
             s->prof_end(0, (double)B * c.vocab * 4);
         }
         std::vector<uint32_t> hlo(npairs), hhi(npairs);
@@ -524,7 +524,7 @@ cz_status cz_rwkv7_decode_group(cz_session* s, int B, const uint8_t* const* payl
     CZCHK(rw_step(s, B));                                            // step(bos) (src/main.rs:2485 equivalent for rwkv)
     for (size_t i = 0; i < max_tc; ++i) {
         s->prof_begin(PK_DECODE);
-        HIPCHK(cz_launch_decode_symbol(s->stream, m->logits, c.vocab, dst, m->sym, B, c.vocab, 1, (unsigned long long)i, s->fallback_dev, nullptr));
+        HIPCHK(cz_launch_decode_symbol(s->stream, m->logits, c.vocab, dst, m->sym, B, c.vocab, 1, (unsigned long long)i, s->fallback_dev, nullptr, s->cdf_scratch));
         s->prof_end(0, (double)B * c.vocab * 4);
         if (i + 1 < max_tc) {
             hipLaunchKernelGGL(rw_mask_from_sym_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, dst, m->sym, V, m->tok, m->mask, B, (unsigned long long)i);

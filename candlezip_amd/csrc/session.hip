@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <string>
 #include <vector>
+#include <thread>
+#include <string>
 #include "cz_host.h"
 #include "cz_kernels.h"
 #include "cz_session.h"
@@ -55,10 +57,9 @@ __global__ void gather_hist_kernel(const cz_dec_state* st, uint32_t* tok, int ns
     tok[i] = st[b].out_ids[idx];
 }
 
-static unsigned long long g_devbuf_gen = 0;       // bumped whenever any work buffer moves: captured graphs hold raw pointers
 cz_status DevBuf::ensure(size_t bytes) {
     if (bytes <= cap) return CZ_OK;
-    ++g_devbuf_gen;
+    if (gen) ++*gen;
     if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
     size_t want = bytes + bytes / 8 + 256;
     HIPCHK(hipMalloc(&p, want));
@@ -384,6 +385,16 @@ static cz_status llama_reprime(cz_session* s, int B, int hl) {
     return llama_head(s, (const int*)s->rowidx.p, B, s->step_logits);
 }
 
+// size every packed-row buffer for M rows (and nlog logit rows) now, so that nothing moves later
+static cz_status reserve_rows(cz_session* s, size_t M, size_t nlog) {
+    const cz_llama_config& c = s->llama.cfg;
+    const size_t d = c.d_model, kvd = (size_t)c.n_kv_heads * 64, f = c.d_ffn, nq = d + 2 * kvd;
+    CZCHK(s->x.ensure(M * d * 4)); CZCHK(s->xn.ensure(M * d * 4)); CZCHK(s->qkv.ensure(M * nq * 4));
+    CZCHK(s->gu.ensure(M * 2 * f * 4)); CZCHK(s->h.ensure(M * f * 4)); CZCHK(s->xl.ensure(nlog * d * 4));
+    CZCHK(s->seqd.ensure(nlog * sizeof(cz_seq_desc))); CZCHK(s->roped.ensure(nlog * sizeof(cz_rope_desc))); CZCHK(s->rowidx.ensure(nlog * 4));
+    return CZ_OK;
+}
+
 // One decode iteration as a hipGraph: decode_symbol(i) -> tok = sym -> step(pos) -> ++i, ++pos.  All per-iteration scalars
 // live in HBM (pos_dev), so the same executable graph is replayed for every token; the host only enqueues.
 static void destroy_step_graph(cz_session* s) {
@@ -393,7 +404,7 @@ static void destroy_step_graph(cz_session* s) {
 }
 static cz_status build_step_graph(cz_session* s, int B) {
     destroy_step_graph(s);
-    s->graph_gen = g_devbuf_gen;
+    s->graph_gen = s->devbuf_gen;
     const cz_llama_config& c = s->llama.cfg;
     cz_dec_state* dst = (cz_dec_state*)s->decst.p;
     const unsigned long long* step_dev = reinterpret_cast<const unsigned long long*>(s->pos_dev + 2);
@@ -403,7 +414,7 @@ static cz_status build_step_graph(cz_session* s, int B) {
     if (rc != CZ_OK) { s->prof_on = prof; return rc; }
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    hipError_t e = cz_launch_decode_symbol(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, 0ull, s->fallback_dev, step_dev);
+    hipError_t e = cz_launch_decode_symbol(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, 0ull, s->fallback_dev, step_dev, s->cdf_scratch);
     if (e == hipSuccess) e = hipMemcpyAsync(s->tok.p, s->step_sym, (size_t)B * 4, hipMemcpyDeviceToDevice, s->stream);
     if (e == hipSuccess) rc = llama_step_fast(s, B, 0, CZ_MAX_CTX);
     if (e == hipSuccess && rc == CZ_OK) { hipLaunchKernelGGL(inc_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev); e = hipGetLastError(); }
@@ -503,7 +514,7 @@ static cz_status encode_llama(cz_session* s, size_t n_streams, const uint32_t* c
             if (s->serial_cdf) HIPCHK(cz_launch_cdf_pairs_serial(s->stream, (const float*)s->logits.p, c.vocab, (const uint32_t*)s->sym.p + r0,
                                                                   (uint32_t*)s->clo.p + r0, (uint32_t*)s->chi.p + r0, nr, c.vocab, 0));
             else HIPCHK(cz_launch_cdf_pairs(s->stream, (const float*)s->logits.p, c.vocab, (const uint32_t*)s->sym.p + r0, (uint32_t*)s->clo.p + r0,
-                                            (uint32_t*)s->chi.p + r0, nr, c.vocab, 0, s->fallback_dev));
+                                            (uint32_t*)s->chi.p + r0, nr, c.vocab, 0, s->fallback_dev, s->cdf_scratch));
             s->prof_end(0, (double)nr * c.vocab * 4);
         }
         std::vector<uint32_t> lo(Lr), hi(Lr);
@@ -542,6 +553,10 @@ static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* 
     HIPCHK(cz_launch_dec_init(s->stream, dst, B));                                           // ArithmeticDecoder::new (:2485)
     hipLaunchKernelGGL(init_out_ids_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, dst, B, bos);
     CZCHK(s->tok.ensure((size_t)B * CZ_MAX_CTX * 4));
+    {   // the captured step graph holds raw pointers: size the buffers of every later re-prime before it is built
+        size_t ec0 = context_window > 0 ? context_window - 1 : 0; if (ec0 > 511) ec0 = 511;
+        if (max_tc > R && ec0 > 0) CZCHK(reserve_rows(s, (size_t)B * ec0, (size_t)B));
+    }
     hipLaunchKernelGGL(fill_u32_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, (uint32_t*)s->tok.p, bos, B);
     hipLaunchKernelGGL(fill_u32_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, s->step_sym, bos, B);   // finished streams keep a valid id
     s->index_pos = 0;                                                                        // the single-stream step state is reset
@@ -552,9 +567,9 @@ static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* 
     const unsigned dec_kinds = (1u << PK_DECODE) | (1u << PK_DEC_GEMM) | (1u << PK_DEC_ATTN) | (1u << PK_DEC_NORM) | (1u << PK_EMBED);
     const bool prof_decode = s->prof_on && (s->prof_mask & dec_kinds);
     const bool use_graph = !s->no_graph && !s->decode_v1 && !s->serial_cdf && !prof_decode && c.n_heads / c.n_kv_heads <= 4;
-    if (use_graph && (s->graph_B != B || s->graph_gen != g_devbuf_gen)) {
+    if (use_graph && (s->graph_B != B || s->graph_gen != s->devbuf_gen)) {
         CZCHK(build_step_graph(s, B));
-        if (s->graph_gen != g_devbuf_gen) CZCHK(build_step_graph(s, B));                     // the dry run itself grew a buffer: capture again
+        if (s->graph_gen != s->devbuf_gen) CZCHK(build_step_graph(s, B));                     // the dry run itself grew a buffer: capture again
         CZCHK(llama_step(s, B, 0));                                                          // the dry run clobbered the BOS logits
     }
     const unsigned long long* step_dev = reinterpret_cast<const unsigned long long*>(s->pos_dev + 2);
@@ -566,6 +581,7 @@ static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* 
             hipLaunchKernelGGL(gather_hist_kernel, dim3((unsigned)((B * hl + 255) / 256)), dim3(256), 0, s->stream, dst, (uint32_t*)s->tok.p, B, (int)hl,
                                (unsigned long long)end);
             CZCHK(llama_reprime(s, B, (int)hl));
+            if (use_graph && s->graph_gen != s->devbuf_gen) { cz_set_error("internal: a work buffer moved under the captured decode graph"); return CZ_ERR_STATE; }
             index_pos = hl;
             hipLaunchKernelGGL(set_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, (int)index_pos, (unsigned long long)i);
         }
@@ -575,7 +591,7 @@ static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* 
         } else {
             s->prof_begin(PK_DECODE);
             if (s->serial_cdf) HIPCHK(cz_launch_decode_symbol_serial(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, (unsigned long long)i, nullptr));
-            else HIPCHK(cz_launch_decode_symbol(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, (unsigned long long)i, s->fallback_dev, nullptr));
+            else HIPCHK(cz_launch_decode_symbol(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, (unsigned long long)i, s->fallback_dev, nullptr, s->cdf_scratch));
             s->prof_end(0, (double)B * c.vocab * 4);
             if (i + 1 < max_tc) {
                 // the reference also steps after the last symbol (:2627); its logits are never used, so it is skipped here
@@ -608,14 +624,15 @@ extern "C" cz_status cz_session_open(const cz_model_desc* desc, int device_ordin
     s->backend = desc->backend; s->device = device_ordinal; s->seed = desc->synthetic_seed;
     s->max_streams = desc->max_streams ? (int)desc->max_streams : 64;
     if (s->max_streams > 256) { delete s; cz_set_error("max_streams > 256 is not supported"); return CZ_ERR_ARG; }
-    hipError_t e = hipStreamCreate(&s->stream);
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);   // several sessions may capture/replay graphs concurrently
     if (e != hipSuccess) { delete s; cz_set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return CZ_ERR_HIP; }
     if (hipMalloc((void**)&s->fallback_dev, 64) != hipSuccess || hipMemset(s->fallback_dev, 0, 64) != hipSuccess) { delete s; cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
     cz_status rc = CZ_OK;
     if (desc->backend == CZ_BACKEND_SMOLLM) rc = build_llama(s, desc);
     else if (desc->backend == CZ_BACKEND_RWKV7) rc = cz_rwkv7_build(s, desc);
     else { cz_set_error("unknown backend %d", (int)desc->backend); rc = CZ_ERR_ARG; }      // src/main.rs:1829 "unknown backend"
-    if (rc == CZ_OK && desc->backend == CZ_BACKEND_SMOLLM && cz_cdf_par_prepare(s->llama.cfg.vocab) != hipSuccess) { cz_set_error("cannot allocate CDF scratch"); rc = CZ_ERR_HIP; }
+    if (rc == CZ_OK && desc->backend == CZ_BACKEND_SMOLLM && cz_cdf_par_supported(s->llama.cfg.vocab, 0) &&
+        hipMalloc((void**)&s->cdf_scratch, cz_cdf_par_scratch_bytes(s->llama.cfg.vocab)) != hipSuccess) { cz_set_error("cannot allocate CDF scratch"); rc = CZ_ERR_HIP; }
     if (rc == CZ_OK && cz_dec_attn_prepare(CZ_MAX_CTX) != hipSuccess) { cz_set_error("cannot reserve LDS for decode attention"); rc = CZ_ERR_HIP; }
     if (rc == CZ_OK && cz_attention_prepare(CZ_MAX_CTX) != hipSuccess) { cz_set_error("cannot reserve LDS for attention"); rc = CZ_ERR_HIP; }
     if (rc != CZ_OK) { cz_session_close(s); return rc; }
@@ -625,6 +642,9 @@ extern "C" cz_status cz_session_open(const cz_model_desc* desc, int device_ordin
 extern "C" void cz_session_close(cz_session* s) {
     if (!s) return;
     hipSetDevice(s->device);
+    for (cz_session* l : s->lanes) cz_session_close(l);
+    s->lanes.clear();
+    if (s->is_lane) { s->llama.blob = s->llama.blob_dec = nullptr; s->llama.rope_cos = s->llama.rope_sin = nullptr; }   // the weights belong to the parent
     if (s->stream) hipStreamSynchronize(s->stream);
     destroy_step_graph(s);
     s->prof_drain();
@@ -632,7 +652,7 @@ extern "C" void cz_session_close(cz_session* s) {
     DevBuf* bufs[] = {&s->tok, &s->x, &s->xn, &s->qkv, &s->gu, &s->h, &s->seqd, &s->roped, &s->rowidx, &s->sym, &s->clo, &s->chi, &s->xl,
                       &s->logits, &s->payload, &s->outids, &s->decst};
     for (auto b : bufs) b->release();
-    void* ptrs[] = {s->fallback_dev, s->llama.blob_dec, s->llama.blob, s->llama.rope_cos, s->llama.rope_sin, s->kvcache, s->pos_dev, s->step_seqd, s->step_roped, s->step_rows,
+    void* ptrs[] = {s->cdf_scratch, s->fallback_dev, s->llama.blob_dec, s->llama.blob, s->llama.rope_cos, s->llama.rope_sin, s->kvcache, s->pos_dev, s->step_seqd, s->step_roped, s->step_rows,
                     s->step_logits, s->step_sym};
     for (auto p : ptrs) if (p) { hipError_t e = hipFree(p); (void)e; }
     cz_rwkv7_destroy(s);
@@ -686,15 +706,59 @@ extern "C" cz_status cz_encode_tokens(cz_session* s, const uint32_t* ids, size_t
                                       uint32_t* out_c_lo, uint32_t* out_c_hi) {
     return cz_encode_tokens_batch(s, 1, &ids, &n, context, reprime_interval, &out_c_lo, &out_c_hi);
 }
+// ---- decode lanes.  One lock-step group is latency-bound (about sixty small dependent kernels per token), so groups beyond
+// the first run concurrently on sessions of their own (stream, KV cache, work buffers, step graph) that share the weights.
+static cz_status make_lane(cz_session* p, cz_session** out) {
+    cz_session* c = new cz_session();
+    c->is_lane = true; c->backend = p->backend; c->device = p->device; c->seed = p->seed; c->max_streams = p->max_streams;
+    c->llama = p->llama;                                   // shallow: same device tensors
+    c->max_lanes = 1;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->fallback_dev, 64) != hipSuccess ||
+        hipMemset(c->fallback_dev, 0, 64) != hipSuccess ||
+        (p->cdf_scratch && hipMalloc((void**)&c->cdf_scratch, cz_cdf_par_scratch_bytes(c->llama.cfg.vocab)) != hipSuccess)) {
+        cz_session_close(c); cz_set_error("cannot allocate a decode lane"); return CZ_ERR_HIP;
+    }
+    *out = c;
+    return CZ_OK;
+}
+static cz_status decode_llama_lanes(cz_session* s, size_t n_streams, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs,
+                                    uint32_t context_window, uint32_t R, uint32_t bos, uint32_t* const* out_ids) {
+    const size_t cap = (size_t)s->max_streams;
+    const size_t G = (n_streams + cap - 1) / cap;
+    // groups of near-equal size, group g = streams [off[g], off[g+1])
+    std::vector<size_t> off(G + 1, 0);
+    for (size_t g = 0; g < G; ++g) off[g + 1] = off[g] + n_streams / G + (g < n_streams % G ? 1 : 0);
+    const size_t L = std::min(G, (size_t)std::max(1, s->max_lanes));
+    while (s->lanes.size() + 1 < L) { cz_session* c = nullptr; CZCHK(make_lane(s, &c)); s->lanes.push_back(c); }
+    std::vector<cz_status> rc(L, CZ_OK); std::vector<std::string> msg(L);
+    auto run = [&](size_t l) {
+        cz_session* ls = l == 0 ? s : s->lanes[l - 1];
+        if (hipSetDevice(s->device) != hipSuccess) { rc[l] = CZ_ERR_HIP; msg[l] = "hipSetDevice failed"; return; }
+        if (l) { ls->serial_cdf = s->serial_cdf; ls->decode_v1 = s->decode_v1; ls->no_graph = s->no_graph; ls->force_big_gemm = s->force_big_gemm;
+                 ls->max_batch_rows = s->max_batch_rows; ls->logit_batch_rows = s->logit_batch_rows; }
+        for (size_t g = l; g < G && rc[l] == CZ_OK; g += L) {
+            rc[l] = decode_llama_group(ls, (int)(off[g + 1] - off[g]), payloads + off[g], lens + off[g], tcs + off[g], context_window, R, bos, out_ids + off[g]);
+            if (rc[l] != CZ_OK) msg[l] = cz_last_error();
+        }
+    };
+    std::vector<std::thread> th;
+    for (size_t l = 1; l < L; ++l) th.emplace_back(run, l);
+    run(0);
+    for (auto& t : th) t.join();
+    for (size_t l = 0; l < L; ++l) if (rc[l] != CZ_OK) { cz_set_error("%s", msg[l].c_str()); return rc[l]; }
+    return CZ_OK;
+}
+
 extern "C" cz_status cz_decode_tokens_batch(cz_session* s, size_t n_streams, const uint8_t* const* payloads, const size_t* lens,
                                             const size_t* token_counts, uint32_t context_window, uint32_t reprime_interval, uint32_t bos,
                                             uint32_t* const* out_ids) {
     if (!s || !payloads || !lens || !token_counts || !out_ids) { cz_set_error("cz_decode_tokens_batch: null argument"); return CZ_ERR_ARG; }
     HIPCHK(hipSetDevice(s->device));
+    if (n_streams == 0) return CZ_OK;
+    if (s->backend != CZ_BACKEND_RWKV7) return decode_llama_lanes(s, n_streams, payloads, lens, token_counts, context_window, reprime_interval, bos, out_ids);
     for (size_t g = 0; g < n_streams; g += (size_t)s->max_streams) {
         const int B = (int)std::min((size_t)s->max_streams, n_streams - g);
-        if (s->backend == CZ_BACKEND_RWKV7) CZCHK(cz_rwkv7_decode_group(s, B, payloads + g, lens + g, token_counts + g, bos, out_ids + g));
-        else CZCHK(decode_llama_group(s, B, payloads + g, lens + g, token_counts + g, context_window, reprime_interval, bos, out_ids + g));
+        CZCHK(cz_rwkv7_decode_group(s, B, payloads + g, lens + g, token_counts + g, bos, out_ids + g));
     }
     return CZ_OK;
 }
@@ -742,6 +806,7 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "decode_v1")) s->decode_v1 = (int)value;
     else if (!strcmp(key, "no_graph")) s->no_graph = (int)value;
     else if (!strcmp(key, "attn_v1")) g_attn_v1 = (int)value;
+    else if (!strcmp(key, "max_lanes")) s->max_lanes = (int)value;
     else { cz_set_error("unknown debug key %s", key); return CZ_ERR_ARG; }
     return CZ_OK;
 }
@@ -753,7 +818,9 @@ extern "C" long cz_debug_get(cz_session* s, const char* key) {
         unsigned v = 0;
         hipStreamSynchronize(s->stream);
         if (hipMemcpy(&v, s->fallback_dev, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        return (long)v;
+        long total = (long)v;
+        for (cz_session* l : s->lanes) { long t = cz_debug_get(l, key); if (t < 0) return -1; total += t; }
+        return total;
     }
     return -1;
 }

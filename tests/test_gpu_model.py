@@ -149,6 +149,30 @@ def test_decode_paths_agree_graph_eager_v1(cz, czo, tiny_pair):
     assert g.debug_get("cdf_fallback_rows") == 0
 
 
+def test_decode_lanes_and_fresh_session(cz, czo, tiny_pair):
+    """more streams than one lock-step group holds: the groups run concurrently on decode lanes (own HIP stream, KV cache and
+    step graph, shared weights) and must return exactly what one group at a time returns; the decoding session is FRESH (never
+    encoded), so the buffers of its first re-prime are the ones reserved before the step graph is captured."""
+    g, o = tiny_pair
+    rng = np.random.default_rng(21)
+    lens = [700, 40, 1300, 1, 0, 650, 1100, 513, 900, 64, 1250]
+    streams = [np.concatenate([[0], rng.integers(0, 512, n)]).astype(np.uint32) for n in lens]
+    pays = []
+    for s in streams:
+        lo, hi = g.encode_tokens(s)
+        pays.append(cz.ac_encode_pairs(lo, hi)[0])
+    cfg = cz.tiny_llama_config()
+    for lanes in (1, 2, 4):
+        f = cz.Session("smollm", cfg, seed=11, embed_std=0.05, max_streams=3)     # 11 streams -> 4 groups of 3,3,3,2
+        f.debug_set("max_lanes", lanes)
+        outs = f.decode_tokens_batch(pays, [s.size - 1 for s in streams])
+        outs2 = f.decode_tokens_batch(pays[::-1], [s.size - 1 for s in streams[::-1]])   # graphs and lanes are reused
+        assert f.debug_get("cdf_fallback_rows") == 0
+        f.close()
+        for s, out, out2 in zip(streams, outs, outs2[::-1]):
+            assert np.array_equal(s, out) and np.array_equal(s, out2), lanes
+
+
 # ---------------------------------------------------------------- RWKV7 (config 4: recurrent-state kernel path)
 @pytest.fixture(scope="module")
 def rwkv_pair(cz, czo):
