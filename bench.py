@@ -40,6 +40,40 @@ def note(msg):
 _T0 = time.perf_counter()
 
 
+# kernel-family name (cz_profile_read) -> rocprofv3 kernel names
+FAMILY_KERNELS = {
+    "dec_attention": ["dec_attn_kernel<3>"], "dec_gemm_plain": ["dec_gemm_kernel<0, 0, 1>"], "dec_gemm_qkv_rope": ["dec_gemm_kernel<1, 1, 1>"],
+    "dec_gemm_swiglu": ["dec_gemm_kernel<2, 0, 2>"], "dec_gemm_lm_head": ["dec_gemm_kernel<0, 0, 8>"], "dec_rmsnorm": ["dec_rmsnorm_kernel"],
+    "decode_symbol": ["cdf_par_kernel<1>"], "cdf_pairs": ["cdf_par_kernel<0>"],
+    "gemm_bf16w_f32_mfma": ["gemm_bf16w_kernel<128, 128, 2, 2>"], "gemm_bf16w_f32_mfma_n64": ["gemm_bf16w_kernel<128, 64, 2, 2>"],
+    "attention_f32_mfma": ["attention_v2_kernel<3, 16>", "attention_v2_kernel<3, 8>"],
+}
+
+
+def pmc_traffic(family):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc passes (profiles/r*_pmc_*_pmc.json, made by
+    tools/prof_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same bench in eager mode).  FETCH_SIZE / WRITE_SIZE
+    are in KiB; on gfx950 FETCH_SIZE counts 128-B requests of wide coalesced reads at 64 B, so it is doubled (MI355X_MICROARCH.md,
+    "HBM").  Returns (bytes_per_launch or None, note)."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    tot = 0.0; notes = []
+    for counter, scale in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
+        files = sorted(glob.glob(os.path.join(here, "profiles", f"r*_pmc_{counter}_pmc.json")))
+        if not files:
+            notes.append(f"{counter}: no pass committed")
+            continue
+        d = json.load(open(files[-1]))
+        disp = sum(d[k][counter]["dispatches"] for k in FAMILY_KERNELS.get(family, []) if k in d and counter in d[k])
+        val = sum(d[k][counter]["sum"] for k in FAMILY_KERNELS.get(family, []) if k in d and counter in d[k])
+        if not disp:
+            notes.append(f"{counter}: kernel not in {os.path.basename(files[-1])}")
+            continue
+        tot += val * scale / disp
+        notes.append(f"{counter} from {os.path.basename(files[-1])} ({disp} dispatches{', x2 gfx950 correction' if counter == 'FETCH_SIZE' else ''})")
+    return (round(tot) if tot else None), "; ".join(notes)
+
+
 def self_test_step(cz, sess, streams, context, reprime):
     """compress + decompress of every stream; returns (tokens, payload_bytes, t_encode, t_decode)"""
     t0 = time.perf_counter()
@@ -86,11 +120,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=128, help="streams (64 KiB chunks) per GPU, decoded in lock-step")
-    ap.add_argument("--lanes", type=int, default=4, help="concurrent lock-step decode groups per GPU (library decode lanes)")
+    ap.add_argument("--streams", type=int, default=384, help="streams (64 KiB chunks) per GPU, decoded in lock-step")
+    ap.add_argument("--lanes", type=int, default=3, help="concurrent lock-step decode groups per GPU (library decode lanes)")
+    ap.add_argument("--no-graph", action="store_true", help="launch the decode step eagerly (needed under rocprofv3 --pmc)")
+    ap.add_argument("--dec-grid-target", type=int, default=0, help="tuning: blocks per decode GEMM launch (0 = library default)")
     ap.add_argument("--lane-streams", type=int, default=128, help="streams per lock-step group")
     ap.add_argument("--warmup-tokens", type=int, default=1100, help="tokens/stream of a warmup step")
-    ap.add_argument("--profile-tokens", type=int, default=1100, help="tokens/stream of the untimed per-family profiling pass")
+    ap.add_argument("--profile-tokens", type=int, default=600, help="tokens/stream of the untimed per-family profiling pass")
     ap.add_argument("--tokens", type=int, default=17408, help="tokens per stream (~ one 64 KiB enwik8 sample)")
     ap.add_argument("--context", type=int, default=512)
     ap.add_argument("--reprime-interval", type=int, default=512)
@@ -110,6 +146,10 @@ def main():
     cfg = cz.tiny_llama_config() if args.tiny else cz.smollm2_135m_config()
     sess = cz.Session("smollm", cfg, seed=0x5EED, embed_std=0.02, device=local, max_streams=min(256, args.streams, args.lane_streams))
     sess.debug_set("max_lanes", args.lanes)
+    if args.no_graph:
+        sess.debug_set("no_graph", 1)
+    if args.dec_grid_target:
+        sess.debug_set("dec_grid_target", args.dec_grid_target)
     streams = make_streams(rank, args.streams, args.tokens, cfg.vocab)   # files shard across ranks: no data-path collective
     note(f"rank {rank}/{world}: session open, {args.streams} streams x {args.tokens} tokens")
 
@@ -128,7 +168,7 @@ def main():
 
     # timed region: exactly K steps.  The big-M MFMA GEMM family (launched eagerly) is HIP-event timed on the library's
     # stream inside this region; the decode-step kernels run inside hipGraphs and cannot be bracketed one by one.
-    sess.profile_enable(True, only=["gemm_bf16w_f32_mfma"])
+    sess.profile_enable(True, only=["gemm_bf16w_f32_mfma", "gemm_bf16w_f32_mfma_n64"])
     barrier()
     t0 = time.perf_counter()
     tok = byt = 0; te = td = 0.0
@@ -141,9 +181,11 @@ def main():
 
     # per-family pass (untimed, eager, every family HIP-event timed) on the same streams cut to `--profile-tokens` tokens:
     # names the dominant kernel family and measures its achieved roofline
+    # (one lock-step group alone on the device, so that the per-launch durations are not inflated by the other decode lanes)
     sess.profile_enable(True)
-    short = [s[: args.profile_tokens + 1] for s in streams]
-    self_test_step(cz, sess, short, args.context, args.reprime_interval)
+    short = [s[: args.profile_tokens + 1] for s in streams[: min(args.streams, args.lane_streams)]]
+    if args.profile_tokens > 0:
+        self_test_step(cz, sess, short, args.context, args.reprime_interval)
     prof_all = sess.profile_read()
     sess.profile_enable(False)
     dominant = max(prof_all, key=lambda k: prof_all[k]["total_ms"]) if prof_all else "gemm_bf16w_f32_mfma"
@@ -165,12 +207,19 @@ def main():
             else:
                 ach = st["bytes"] / (st["total_ms"] * 1e-3) / 1e9 if st["total_ms"] else 0.0
                 r = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5)}
-            r.update({"traffic": None, "kernel": name, "launches": st["launches"], "avg_launch_us": round(1e3 * st["total_ms"] / max(st["launches"], 1), 3)})
+            traffic, tnote = pmc_traffic(name)
+            r.update({"traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": tnote,
+                      "algorithmic_per_launch": round((st["flops"] if r["bound"] == "mfma" else st["bytes"]) / max(st["launches"], 1)), "kernel": name, "launches": st["launches"], "avg_launch_us": round(1e3 * st["total_ms"] / max(st["launches"], 1), 3)})
             return r
         roof = roof_of(dominant, prof_all.get(dominant, {"launches": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0}))
-        roof["measured_in"] = f"eager per-family pass inside bench.py ({args.profile_tokens} tokens/stream); the timed region replays hipGraphs"
+        roof["measured_in"] = (f"eager per-family pass inside bench.py ({len(short)} streams x {args.profile_tokens} tokens, one decode lane); "
+                               "the timed region replays hipGraphs on concurrent lanes")
         roof["families_ms_profile_pass"] = {k: round(v["total_ms"], 2) for k, v in prof_all.items()}
-        roof_gemm = roof_of("gemm_bf16w_f32_mfma", prof_timed.get("gemm_bf16w_f32_mfma", {"launches": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0}))
+        zero = {"launches": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0}
+        both = {k: prof_timed.get("gemm_bf16w_f32_mfma", zero)[k] + prof_timed.get("gemm_bf16w_f32_mfma_n64", zero)[k] for k in zero}
+        roof_gemm = roof_of("gemm_bf16w_f32_mfma", both)
+        roof_gemm["kernel"] = "gemm_bf16w_kernel<128,128> + <128,64> (both tile shapes of the big-M GEMM)"
+        roof_gemm["traffic"] = None; roof_gemm["traffic_source"] = "see roofline (per-kernel PMC numbers are in profiles/)"
         roof_gemm["measured_in"] = "HIP events over the timed region"
         line = {
             "metric": "tokens/sec, enwik8 self-test (compress+decompress), smollm",

@@ -20,6 +20,7 @@ import time
 import numpy as np
 
 import candlezip_amd as cz
+from candlezip_amd import watchdog
 
 _AGENT_FLAGS = ["--scan", "--agent", "--scan-attribution", "--scan-verbose"]
 _AGENT_OPTS = ["--scan-chunk-size", "--scan-max-steps", "--scan-max-hint-tokens", "--scan-mcp-config", "--scan-output-dir", "--scan-python",
@@ -174,6 +175,7 @@ def compress(args, inp, outp, model=None):
     data = open(inp, "rb").read()
     ids = np.concatenate([[m.bos], m.tokenize(data, args)]).astype(np.uint32)          # :1850-1866
     lo, hi = m.sess.encode_tokens(ids, args.context, args.reprime_interval)
+    m.trace = {"encode_ids": ids[1:].copy(), "c_lo": lo, "c_hi": hi}                   # watchdog-lite (watchdog.py)
     payload, zero_width = cz.ac_encode_pairs(lo, hi)
     if zero_width:
         print(f"warning: {zero_width} token(s) have a zero-width coding interval (p < 2^-30): like the reference's, this file will NOT decode", file=sys.stderr)
@@ -209,6 +211,8 @@ def decompress(args, inp, outp, model=None):
         if m.tok_hash != bytes(h.tokenizer_hash16):
             sys.exit("tokenizer hash mismatch. Use --force-mismatch to override.")
     ids = m.sess.decode_tokens(buf[n:], int(h.token_count), h.context_window, h.reprime_interval, h.bos_token_id)
+    if getattr(m, "trace", None) is not None:
+        m.trace["decode_ids"] = ids[1:].copy()
     if args.token_ids and outp.endswith(".ids"):
         ids[1:].astype("<u4").tofile(outp)
     else:
@@ -228,10 +232,26 @@ def self_test(args, inp):
     print(f"Compression   : {t1 - t0:.2f}s")                                            # :191-193
     print(f"Decompression : {t2 - t1:.2f}s")
     print(f"Bits per byte : {8.0 * len(enc) / max(len(src), 1):.3f}")
+    if watchdog.enabled() and getattr(m, "trace", None) and "decode_ids" in m.trace:
+        d = watchdog.run_dir(inp, args.backend)
+        watchdog.write_steps(d, "watchdog_encode_steps.jsonl", m.trace["encode_ids"], "encode")
+        watchdog.write_steps(d, "watchdog_decode_steps.jsonl", m.trace["decode_ids"], "decode")
     if src == got:
         print(f"Roundtrip OK. Encoded: {len(enc)} bytes, Decoded: {len(got)} bytes")
         return 0
-    print("roundtrip mismatch", file=sys.stderr)
+    print("[watchdog] Roundtrip mismatch detected. Collecting diagnostics...", file=sys.stderr)       # :195
+    tr = getattr(m, "trace", None) or {}
+    if "encode_ids" in tr and "decode_ids" in tr:
+        d = watchdog.run_dir(inp, args.backend)
+        watchdog.write_steps(d, "watchdog_encode_steps.jsonl", tr["encode_ids"], "encode")
+        watchdog.write_steps(d, "watchdog_decode_steps.jsonl", tr["decode_ids"], "decode")
+        rec = watchdog.report(d, tr["encode_ids"], tr["decode_ids"], tr.get("c_lo"), tr.get("c_hi"))
+        if rec:
+            print(f"[watchdog] first differing symbol at i={rec['i']}: encode_sym={rec['encode_sym']} decode_sym={rec['decode_sym']}"
+                  f" (zero-width coding intervals: {rec.get('zero_width_total', 0)}, first at {rec.get('zero_width_steps', [])[:4]}); report in {d}",
+                  file=sys.stderr)
+        else:
+            print("[watchdog] token ids round-trip exactly: the difference is in (de)tokenisation of the text", file=sys.stderr)
     return 1
 
 

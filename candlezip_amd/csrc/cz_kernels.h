@@ -41,7 +41,7 @@ hipError_t cz_attention_prepare(int max_nk);
 hipError_t cz_launch_cdf_pairs(hipStream_t st, const float* logits, int ld, const uint32_t* sym, uint32_t* c_lo, uint32_t* c_hi,
                                int rows, int vocab, int mode, unsigned* fallback_count, double* scratch);
 #define CZ_CDF_PAR_MAX_GRID 1024
-size_t cz_cdf_par_scratch_bytes(int vocab);     // the `scratch` the exact-parallel CDF launchers need (owned by the session)
+size_t cz_cdf_par_scratch_bytes(int vocab, int mode);     // the `scratch` the exact-parallel CDF launchers need (owned by the session)
 hipError_t cz_launch_cdf_pairs_serial(hipStream_t st, const float* logits, int ld, const uint32_t* sym, uint32_t* c_lo, uint32_t* c_hi,
                                       int rows, int vocab, int mode);
 bool cz_cdf_par_supported(int vocab, int mode);

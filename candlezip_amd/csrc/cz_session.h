@@ -15,7 +15,7 @@ struct DevBuf {
     void release();
 };
 
-enum ProfKind { PK_GEMM = 0, PK_GEMM_SKINNY, PK_ATTN, PK_RMSNORM, PK_ROPE, PK_SWIGLU, PK_EMBED, PK_CDF, PK_DECODE, PK_RWKV, PK_DEC_GEMM, PK_DEC_ATTN, PK_DEC_NORM, PK_COUNT };
+enum ProfKind { PK_GEMM = 0, PK_GEMM_SKINNY, PK_ATTN, PK_RMSNORM, PK_ROPE, PK_SWIGLU, PK_EMBED, PK_CDF, PK_DECODE, PK_RWKV, PK_DEC_GEMM, PK_DEC_ATTN, PK_DEC_NORM, PK_DEC_GEMM_QKV, PK_DEC_GEMM_GU, PK_DEC_GEMM_HEAD, PK_GEMM_N64, PK_COUNT };
 struct ProfAcc { uint64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
 struct ProfEvt { hipEvent_t e0, e1; int kind; double flops, bytes; };
 
@@ -45,7 +45,7 @@ struct cz_session {
     size_t max_batch_rows = 98304, logit_batch_rows = 8192;
     int force_big_gemm = 0, serial_cdf = 0, decode_v1 = 0, no_graph = 0;
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; int graph_B = 0; unsigned long long graph_gen = 0;
-    unsigned long long devbuf_gen = 0;
+    unsigned long long devbuf_gen = 0, graph_launch_ns = 0, graph_launch_cpu_ns = 0, graph_launch_idle_ns = 0; int probe_launch = 0;
     unsigned* fallback_dev = nullptr;   // rows the exact-parallel CDF kernel handed to the serial walk
     double* cdf_scratch = nullptr;      // spill rows of the exact-parallel CDF kernel (cz_cdf_par_scratch_bytes)
     // decode lanes: independent lock-step groups replayed concurrently on their own HIP streams (share the weights)

@@ -19,7 +19,8 @@
 #include "cz_cdf_common.h"
 
 #define T_PAR 1024
-#define LMAX 48
+#define LMAX_SMOLLM 48                 // 1024 x 48 = 49 152 symbols (SmolLM2)
+#define LMAX_RWKV 66                   // 1024 x 66 >= 65 536 + 256 symbols (RWKV World vocabulary + literal bytes)
 #define NWAVE (T_PAR / 64)
 #define POOL_SLOTS 48
 #define B_INVALID (-100000)
@@ -35,7 +36,7 @@ __device__ __forceinline__ uint32_t quantize_u(double acc) {   // src/main.rs:81
     return (uint32_t)f;
 }
 
-struct par_smem {
+template <int LMAX> struct par_smem_t {
     double sD0[T_PAR], sD1[T_PAR];   // inclusive segmented scan of the chunk transducers (delta for start parity 0 / 1)
     double segacc[T_PAR];            // exact acc at the start of the segment headed by chunk t; later: exact acc_in of chunk t
     int bexp[T_PAR];                 // binade of a chunk's transducer, B_INVALID (no transducer) or B_EMPTY
@@ -56,7 +57,7 @@ struct par_smem {
     int ok;
 };
 
-__device__ __forceinline__ double block_excl_scan(double v, par_smem& sm) {     // approximate (any order): only guesses binades
+template <class SM> __device__ __forceinline__ double block_excl_scan(double v, SM& sm) {     // approximate (any order): only guesses binades
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double inc = v;
 #pragma unroll
@@ -84,8 +85,8 @@ __device__ __forceinline__ tdx td_compose(const tdx& f, const tdx& g) {
 // Exact left-to-right sum of the block's terms xf(k) (thread t owns terms first..first+cnt-1, k < cnt <= LMAX).
 // Returns the exact total; with want_acc_in also the exact running sum before this thread's first term.
 // csum = APPROXIMATE sum of this thread's terms (any rounding; it only feeds the binade guesses).
-template <typename XF>
-__device__ __forceinline__ double exact_seq_sum(XF xf, double csum, int cnt, int first, par_smem& sm, double* scratch, bool want_acc_in,
+template <int LMAX, typename XF>
+__device__ __forceinline__ double exact_seq_sum(XF xf, double csum, int cnt, int first, par_smem_t<LMAX>& sm, double* scratch, bool want_acc_in,
                                                 double* acc_in_out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) sm.pool_next = 0;
@@ -212,20 +213,26 @@ __device__ __forceinline__ double exact_seq_sum(XF xf, double csum, int cnt, int
 
 // DECODE = 0: coder interval of sym[row] for `rows` rows (grid-stride over rows).
 // DECODE = 1: one block per stream: decode a symbol, update the device-resident decoder state.
-template <int DECODE>
+// MODE = 0: SmolLM (softmax_pdf + quantize_pdf_to_cdf, two chains over V terms).
+// MODE = 1: RWKV with literals (softmax_pdf_floor + combined_pdf_with_literals + the inline quantiser, src/main.rs:758-782,
+//           2303-2325): FOUR sequential f64 chains — sum of exps (V), sum of floored probabilities (V), sum of the scaled
+//           distribution with its 256 literal entries (V+256), running cdf (V+256) — each evaluated exactly in parallel.
+template <int DECODE, int MODE, int LMAX>
 __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict__ logits, int ld, int rows, int V,
                                                         const uint32_t* __restrict__ sym, uint32_t* __restrict__ c_lo,
                                                         uint32_t* __restrict__ c_hi, double* __restrict__ scratch_all,
                                                         cz_dec_state* __restrict__ dst, uint32_t* __restrict__ sym_out,
                                                         unsigned long long step_i, unsigned* __restrict__ fallback_count,
                                                         const unsigned long long* __restrict__ step_dev) {
-    __shared__ par_smem sm;
+    __shared__ par_smem_t<LMAX> sm;
     if (DECODE && step_dev) step_i = *step_dev;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double* scratch = scratch_all + (size_t)blockIdx.x * V;
-    const int L = (V + T_PAR - 1) / T_PAR;
+    const int n = MODE ? V + 256 : V;                              // symbols of the coded alphabet
+    double* scratch = scratch_all + (size_t)blockIdx.x * n;
+    const int L = (n + T_PAR - 1) / T_PAR;
     const int first = tid * L;
-    const int cnt = first >= V ? 0 : (V - first < L ? V - first : L);
+    const int cntA = first >= V ? 0 : (V - first < L ? V - first : L);       // owned vocabulary entries (terms of the chains over V)
+    const int cnt = first >= n ? 0 : (n - first < L ? n - first : L);        // owned symbols (vocabulary, then literals)
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
         cz_dec_state d;
         if (DECODE) {
@@ -236,11 +243,11 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
             }
         }
         const float* l = logits + (size_t)row * ld;
-        if (tid == 0) { sm.flag = 0; sm.L = L; sm.n = V; sm.found = (unsigned)V - 1u; sm.ok = 1; }
+        if (tid == 0) { sm.flag = 0; sm.L = L; sm.n = V; sm.found = (unsigned)n - 1u; sm.ok = 1; }
         float ef[LMAX];
         float m = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < LMAX; ++k) if (k < cnt) { ef[k] = l[first + k]; if (ef[k] > m) m = ef[k]; }
+        for (int k = 0; k < LMAX; ++k) if (k < cntA) { ef[k] = l[first + k]; if (ef[k] > m) m = ef[k]; }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { float y = __shfl_xor(m, o); m = y > m ? y : m; }
         if (lane == 0) sm.redf[wave] = m;
@@ -250,17 +257,47 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
         for (int w = 1; w < NWAVE; ++w) m = sm.redf[w] > m ? sm.redf[w] : m;
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < LMAX; ++k) if (k < cnt) ef[k] = cz_expf(ef[k] - m);
+        for (int k = 0; k < LMAX; ++k) if (k < cntA) ef[k] = cz_expf(ef[k] - m);
         double csum_e = 0.0;
 #pragma unroll
-        for (int k = 0; k < LMAX; ++k) if (k < cnt) csum_e += (double)ef[k];
-        const double sum = exact_seq_sum([&](int k) { return (double)ef[k]; }, csum_e, cnt, first, sm, scratch, false, nullptr);
+        for (int k = 0; k < LMAX; ++k) if (k < cntA) csum_e += (double)ef[k];
+        const double sum = exact_seq_sum<LMAX>([&](int k) { return (double)ef[k]; }, csum_e, cntA, first, sm, scratch, false, nullptr);
         bool fallback = sm.flag != 0 || !(sum > 0.0);            // sum <= 0 (uniform pdf, :794) or NaN: take the serial walk
         double acc = 0.0;
-        // pdf term k of this thread, exactly as the reference computes it (:799): exps[i] / sum  (recomputed, not stored: registers)
-        auto pd = [&](int k) { return (double)ef[k] / sum; };
-        if (!fallback) {
-            exact_seq_sum(pd, csum_e / sum, cnt, first, sm, scratch, true, &acc);
+        // MODE 0: pdf term k of this thread, exactly as the reference computes it (:799): exps[i] / sum (recomputed, not stored: registers)
+        // MODE 1: the same through the floor (:763), the renormalisation (:765), the literal mix (:770-780)
+        double norm = 1.0, sum2 = 0.0;
+        const double p_escape_total = 256.0 * P_MIN;             // :771
+        const double scale = (1.0 - p_escape_total) > 0.0 ? (1.0 - p_escape_total) : 0.0;
+        const double lit = p_escape_total > 0.0 ? p_escape_total / 256.0 : 0.0;
+        auto fl = [&](int k) { const double p = (double)ef[k] / sum; return p > P_MIN ? p : P_MIN; };            // (exps/sum).max(p_floor)
+        auto mix = [&](int k) { return k < cntA ? (fl(k) / norm) * scale : lit; };                                 // base[i] /= norm; *= scale | literal
+        auto pd = [&](int k) {
+            if (MODE == 0) return (double)ef[k] / sum;
+            const double x = mix(k);
+            return sum2 > 0.0 ? x / sum2 : x;                                                                    // :779
+        };
+        if (MODE == 1 && !fallback) {
+            double cs = 0.0;
+#pragma unroll
+            for (int k = 0; k < LMAX; ++k) if (k < cntA) cs += fl(k);
+            norm = exact_seq_sum<LMAX>(fl, cs, cntA, first, sm, scratch, false, nullptr);
+            fallback = sm.flag != 0 || !(norm > 0.0);
+            if (!fallback) {
+                if (tid == 0) sm.n = n;                          // the last two chains run over vocabulary + literals
+                double cs2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < LMAX; ++k) if (k < cnt) cs2 += mix(k);
+                sum2 = exact_seq_sum<LMAX>(mix, cs2, cnt, first, sm, scratch, false, nullptr);
+                fallback = sm.flag != 0 || !(sum2 > 0.0);
+                if (!fallback) {
+                    exact_seq_sum<LMAX>(pd, cs2 / sum2, cnt, first, sm, scratch, true, &acc);
+                    fallback = sm.flag != 0;
+                }
+            }
+        }
+        if (MODE == 0 && !fallback) {
+            exact_seq_sum<LMAX>(pd, csum_e / sum, cnt, first, sm, scratch, true, &acc);
             fallback = sm.flag != 0;
         }
         if (fallback) {                                          // rare: exact serial walk by one lane
@@ -268,12 +305,12 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
                 if (fallback_count) atomicAdd(fallback_count, 1u);
                 if (DECODE) {
                     uint32_t s = 0;
-                    if (serial_decode_row(l, V, 0, d, &s)) { d.out_ids[step_i + 1] = s; sym_out[row] = s; }
+                    if (serial_decode_row(l, V, MODE, d, &s)) { d.out_ids[step_i + 1] = s; sym_out[row] = s; }
                     else { d.active = 0; sym_out[row] = 0; }
                     dst[row] = d;
                 } else {
                     uint32_t lo, hi;
-                    serial_pairs_row(l, V, 0, sym[row], &lo, &hi);
+                    serial_pairs_row(l, V, MODE, sym[row], &lo, &hi);
                     c_lo[row] = lo; c_hi[row] = hi;
                 }
             }
@@ -284,14 +321,14 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
         if (!DECODE) {
             const uint32_t s = sym[row];
             if (tid == 0 && s == 0) c_lo[row] = 0;
-            if (tid == 0 && s >= (uint32_t)V) { c_lo[row] = 0; c_hi[row] = 0; }
+            if (tid == 0 && s >= (uint32_t)n) { c_lo[row] = 0; c_hi[row] = 0; }
 #pragma unroll
             for (int k = 0; k < LMAX; ++k)
                 if (k < cnt) {
                     acc = acc + pd(k);
                     const uint32_t i = (uint32_t)(first + k);
                     if (i == s || i + 1 == s) {
-                        const uint32_t v = (i + 1 == (uint32_t)V) ? CDF_TOTAL_U : quantize_u(acc);   // cdf[n] = total forced (:822)
+                        const uint32_t v = (i + 1 == (uint32_t)n) ? CDF_TOTAL_U : quantize_u(acc);   // cdf[n] = total forced (:822, :2321)
                         if (i == s) c_hi[row] = v; else c_lo[row] = v;
                     }
                 }
@@ -311,7 +348,7 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
                 if (k < cnt) {
                     acc = acc + pd(k);
                     const uint32_t i = (uint32_t)(first + k);
-                    const uint32_t v = (i + 1 == (uint32_t)V) ? CDF_TOTAL_U : quantize_u(acc);
+                    const uint32_t v = (i + 1 == (uint32_t)n) ? CDF_TOTAL_U : quantize_u(acc);
                     if (v > value && mine == 0xffffffffu) mine = i;
                 }
             if (mine != 0xffffffffu) atomicMin(&sm.found, mine);
@@ -325,7 +362,7 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
                     if (k < cnt) {
                         a = a + pd(k);
                         const uint32_t i = (uint32_t)(first + k);
-                        const uint32_t v = (i + 1 == (uint32_t)V) ? CDF_TOTAL_U : quantize_u(a);
+                        const uint32_t v = (i + 1 == (uint32_t)n) ? CDF_TOTAL_U : quantize_u(a);
                         if (i + 1 == s) lo = v;
                         if (i == s) hi = v;
                     }
@@ -343,7 +380,7 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
     }
 }
 
-bool cz_cdf_par_supported(int vocab, int mode) { return mode == 0 && vocab <= T_PAR * LMAX; }
+bool cz_cdf_par_supported(int vocab, int mode) { return mode == 0 ? vocab <= T_PAR * LMAX_SMOLLM : vocab + 256 <= T_PAR * LMAX_RWKV; }
 
 hipError_t cz_launch_cdf_pairs(hipStream_t st, const float* logits, int ld, const uint32_t* sym, uint32_t* c_lo, uint32_t* c_hi,
                                int rows, int vocab, int mode, unsigned* fallback_count, double* g_scratch) {
@@ -351,8 +388,12 @@ hipError_t cz_launch_cdf_pairs(hipStream_t st, const float* logits, int ld, cons
     if (!cz_cdf_par_supported(vocab, mode)) return cz_launch_cdf_pairs_serial(st, logits, ld, sym, c_lo, c_hi, rows, vocab, mode);
     if (!g_scratch) return hipErrorInvalidValue;
     const int grid = rows < CZ_CDF_PAR_MAX_GRID ? rows : CZ_CDF_PAR_MAX_GRID;
-    hipLaunchKernelGGL(cdf_par_kernel<0>, dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, c_lo, c_hi, g_scratch, nullptr, nullptr, 0ull,
-                       fallback_count, nullptr);
+    if (mode == 0)
+        hipLaunchKernelGGL((cdf_par_kernel<0, 0, LMAX_SMOLLM>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, c_lo, c_hi, g_scratch, nullptr, nullptr,
+                           0ull, fallback_count, nullptr);
+    else
+        hipLaunchKernelGGL((cdf_par_kernel<0, 1, LMAX_RWKV>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, c_lo, c_hi, g_scratch, nullptr, nullptr,
+                           0ull, fallback_count, nullptr);
     return hipGetLastError();
 }
 hipError_t cz_launch_decode_symbol(hipStream_t st, const float* logits, int ld, cz_dec_state* st_arr, uint32_t* sym_out, int nstreams,
@@ -361,9 +402,13 @@ hipError_t cz_launch_decode_symbol(hipStream_t st, const float* logits, int ld, 
     if (nstreams <= 0) return hipSuccess;
     if (!cz_cdf_par_supported(vocab, mode)) return cz_launch_decode_symbol_serial(st, logits, ld, st_arr, sym_out, nstreams, vocab, mode, i, step_dev);
     if (!g_scratch || nstreams > CZ_CDF_PAR_MAX_GRID) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(cdf_par_kernel<1>, dim3(nstreams), dim3(T_PAR), 0, st, logits, ld, nstreams, vocab, nullptr, nullptr, nullptr, g_scratch, st_arr,
-                       sym_out, i, fallback_count, step_dev);
+    if (mode == 0)
+        hipLaunchKernelGGL((cdf_par_kernel<1, 0, LMAX_SMOLLM>), dim3(nstreams), dim3(T_PAR), 0, st, logits, ld, nstreams, vocab, nullptr, nullptr, nullptr, g_scratch,
+                           st_arr, sym_out, i, fallback_count, step_dev);
+    else
+        hipLaunchKernelGGL((cdf_par_kernel<1, 1, LMAX_RWKV>), dim3(nstreams), dim3(T_PAR), 0, st, logits, ld, nstreams, vocab, nullptr, nullptr, nullptr, g_scratch,
+                           st_arr, sym_out, i, fallback_count, step_dev);
     return hipGetLastError();
 }
 // per-session scratch (one spill row per resident block; only touched when a row exhausts the LDS pool)
-size_t cz_cdf_par_scratch_bytes(int vocab) { return (size_t)CZ_CDF_PAR_MAX_GRID * vocab * sizeof(double); }
+size_t cz_cdf_par_scratch_bytes(int vocab, int mode) { return (size_t)CZ_CDF_PAR_MAX_GRID * (vocab + (mode ? 256 : 0)) * sizeof(double); }

@@ -256,12 +256,13 @@ static hipError_t dec_gemm_launch_mt(hipStream_t st, const dec_gemm_args& a, int
     hipLaunchKernelGGL((dec_gemm_kernel<EPI, NORM, MT>), dim3(gx, (a.M + MT * 16 - 1) / (MT * 16)), dim3(64 * NW), smem, st, a);
     return hipGetLastError();
 }
+int g_dec_grid_target = 384;     // tuning knob (cz_debug_set "dec_grid_target")
 template <int EPI, int NORM>
 static hipError_t dec_gemm_launch_n(hipStream_t st, const dec_gemm_args& a, int gx) {
     // row tiles per block: keep the grid near one wave of blocks (<= ~384) while it still has >= 64 of them
     const int mt_all = (a.M + 15) / 16;
     int mt = 1;
-    while (mt < 8 && mt < mt_all && (long)gx * ((mt_all + mt - 1) / mt) > 384) mt *= 2;
+    while (mt < 8 && mt < mt_all && (long)gx * ((mt_all + mt - 1) / mt) > g_dec_grid_target) mt *= 2;
     switch (mt) {
         case 1: return dec_gemm_launch_mt<EPI, NORM, 1>(st, a, gx);
         case 2: return dec_gemm_launch_mt<EPI, NORM, 2>(st, a, gx);

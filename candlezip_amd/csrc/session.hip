@@ -16,12 +16,15 @@
 #include <string>
 #include <vector>
 #include <thread>
+#include <chrono>
+#include <time.h>
 #include <string>
 #include "cz_host.h"
 #include "cz_kernels.h"
 #include "cz_session.h"
 
 extern int g_attn_v1;
+extern int g_dec_grid_target;
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t _e = (expr);                                                                        \
@@ -97,7 +100,8 @@ void cz_session::prof_drain() {
     evts.clear();
 }
 static const char* kProfNames[PK_COUNT] = {"gemm_bf16w_f32_mfma", "gemm_skinny_f32_mfma", "attention_f32_mfma", "rmsnorm", "rope",
-                                           "swiglu", "embed", "cdf_pairs", "decode_symbol", "rwkv7_step", "dec_gemm_f32_mfma", "dec_attention", "dec_rmsnorm"};
+                                           "swiglu", "embed", "cdf_pairs", "decode_symbol", "rwkv7_step", "dec_gemm_plain", "dec_attention", "dec_rmsnorm",
+                                           "dec_gemm_qkv_rope", "dec_gemm_swiglu", "dec_gemm_lm_head", "gemm_bf16w_f32_mfma_n64"};
 
 // ------------------------------------------------------------------ model construction
 static cz_status synth(cz_session* s, uint16_t* dst, const char* name, size_t numel, float stdv, float mean) {
@@ -251,7 +255,7 @@ static cz_status llama_body(cz_session* s, int M, const cz_seq_desc* seqd, const
     hipStream_t st = s->stream;
     const int big = s->force_big_gemm;
     auto gemm = [&](const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R, int N, int K) -> hipError_t {
-        s->prof_begin(M <= 64 && !big ? PK_GEMM_SKINNY : PK_GEMM);
+        s->prof_begin(M <= 64 && !big ? PK_GEMM_SKINNY : (N % 128 ? PK_GEMM_N64 : PK_GEMM));      // 128x64 tiles when N % 128 != 0 (kernels_gemm.hip)
         hipError_t e = cz_launch_gemm(st, A, lda, W, C, ldc, R, ldc, M, N, K, big);
         s->prof_end(2.0 * M * (double)N * K, (double)N * K * 2 + (double)M * (N + K) * 4);
         return e;
@@ -336,7 +340,7 @@ static cz_status llama_step_fast(cz_session* s, int B, int pos, int max_nk) {
     for (int l = 0; l < c.n_layers; ++l) {
         const LlamaModel::Layer& y = m.L[l];
         const size_t kv_off = (size_t)l * s->kv_layer_stride;
-        s->prof_begin(PK_DEC_GEMM);                                                        // RMSNorm(ln1) fused into the A load
+        s->prof_begin(PK_DEC_GEMM_QKV);                                                    // RMSNorm(ln1) fused into the A load
         HIPCHK(cz_launch_dec_gemm_qkv(st, x, d, dec(y.wqkv), q, d, B, d, c.n_heads, c.n_kv_heads, s->step_roped, kv_off, s->pos_dev, m.rope_cos, m.rope_sin,
                                       y.ln1, c.rms_eps));
         s->prof_end(2.0 * B * (double)nq * d, (double)nq * d * 2);
@@ -346,11 +350,11 @@ static cz_status llama_step_fast(cz_session* s, int B, int pos, int max_nk) {
         s->prof_begin(PK_DEC_GEMM); HIPCHK(cz_launch_dec_gemm_plain(st, att, d, dec(y.wo), x, d, x, B, d, d, nullptr, 0.0f)); s->prof_end(2.0 * B * (double)d * d, (double)d * d * 2);
         // wide projections (gate|up, lm_head) have many column blocks: normalise once instead of once per block
         s->prof_begin(PK_DEC_NORM); HIPCHK(cz_launch_dec_rmsnorm(st, x, d, y.ln2, xn, d, B, d, c.rms_eps)); s->prof_end(0, (double)B * d * 8);
-        s->prof_begin(PK_DEC_GEMM); HIPCHK(cz_launch_dec_gemm_swiglu(st, xn, d, dec(y.wgu), h, f, B, f, d, nullptr, 0.0f)); s->prof_end(4.0 * B * (double)f * d, (double)f * d * 4);
+        s->prof_begin(PK_DEC_GEMM_GU); HIPCHK(cz_launch_dec_gemm_swiglu(st, xn, d, dec(y.wgu), h, f, B, f, d, nullptr, 0.0f)); s->prof_end(4.0 * B * (double)f * d, (double)f * d * 4);
         s->prof_begin(PK_DEC_GEMM); HIPCHK(cz_launch_dec_gemm_plain(st, h, f, dec(y.wd), x, d, x, B, d, f, nullptr, 0.0f)); s->prof_end(2.0 * B * (double)d * f, (double)d * f * 2);
     }
     s->prof_begin(PK_DEC_NORM); HIPCHK(cz_launch_dec_rmsnorm(st, x, d, m.lnf, xn, d, B, d, c.rms_eps)); s->prof_end(0, (double)B * d * 8);
-    s->prof_begin(PK_DEC_GEMM);
+    s->prof_begin(PK_DEC_GEMM_HEAD);
     HIPCHK(cz_launch_dec_gemm_plain(st, xn, d, dec(m.E), s->step_logits, c.vocab, nullptr, B, c.vocab, d, nullptr, 0.0f));
     s->prof_end(2.0 * B * (double)c.vocab * d, (double)c.vocab * d * 2 + (double)B * c.vocab * 4);
     return CZ_OK;
@@ -564,7 +568,7 @@ static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* 
     size_t index_pos = 1;
     size_t ec = context_window > 0 ? context_window - 1 : 0; if (ec > 511) ec = 511;         // :2506
     // graph replay unless per-kernel profiling of the decode families is requested or the graph path is disabled
-    const unsigned dec_kinds = (1u << PK_DECODE) | (1u << PK_DEC_GEMM) | (1u << PK_DEC_ATTN) | (1u << PK_DEC_NORM) | (1u << PK_EMBED);
+    const unsigned dec_kinds = (1u << PK_DECODE) | (1u << PK_DEC_GEMM) | (1u << PK_DEC_GEMM_QKV) | (1u << PK_DEC_GEMM_GU) | (1u << PK_DEC_GEMM_HEAD) | (1u << PK_DEC_ATTN) | (1u << PK_DEC_NORM) | (1u << PK_EMBED);
     const bool prof_decode = s->prof_on && (s->prof_mask & dec_kinds);
     const bool use_graph = !s->no_graph && !s->decode_v1 && !s->serial_cdf && !prof_decode && c.n_heads / c.n_kv_heads <= 4;
     if (use_graph && (s->graph_B != B || s->graph_gen != s->devbuf_gen)) {
@@ -587,7 +591,15 @@ static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* 
         }
         if (index_pos >= (size_t)CZ_MAX_CTX) { cz_set_error("position %zu exceeds the supported context (%d)", index_pos, CZ_MAX_CTX); return CZ_ERR_STATE; }
         if (use_graph) {
+            if (s->probe_launch && i < 64) HIPCHK(hipStreamSynchronize(s->stream));          // probe: cost of a launch into an empty queue
+            timespec c0, c1; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c0);
+            const auto t0 = std::chrono::steady_clock::now();
             HIPCHK(hipGraphLaunch(s->graph_exec, s->stream));                                // decode_symbol(i); step(sym) at index_pos; ++i; ++pos
+            const unsigned long long dt = (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c1);
+            s->graph_launch_ns += dt;
+            s->graph_launch_cpu_ns += (unsigned long long)((c1.tv_sec - c0.tv_sec) * 1000000000ll + (c1.tv_nsec - c0.tv_nsec));
+            if (s->probe_launch && i < 64) s->graph_launch_idle_ns += dt;
         } else {
             s->prof_begin(PK_DECODE);
             if (s->serial_cdf) HIPCHK(cz_launch_decode_symbol_serial(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, (unsigned long long)i, nullptr));
@@ -632,7 +644,9 @@ extern "C" cz_status cz_session_open(const cz_model_desc* desc, int device_ordin
     else if (desc->backend == CZ_BACKEND_RWKV7) rc = cz_rwkv7_build(s, desc);
     else { cz_set_error("unknown backend %d", (int)desc->backend); rc = CZ_ERR_ARG; }      // src/main.rs:1829 "unknown backend"
     if (rc == CZ_OK && desc->backend == CZ_BACKEND_SMOLLM && cz_cdf_par_supported(s->llama.cfg.vocab, 0) &&
-        hipMalloc((void**)&s->cdf_scratch, cz_cdf_par_scratch_bytes(s->llama.cfg.vocab)) != hipSuccess) { cz_set_error("cannot allocate CDF scratch"); rc = CZ_ERR_HIP; }
+        hipMalloc((void**)&s->cdf_scratch, cz_cdf_par_scratch_bytes(s->llama.cfg.vocab, 0)) != hipSuccess) { cz_set_error("cannot allocate CDF scratch"); rc = CZ_ERR_HIP; }
+    if (rc == CZ_OK && desc->backend == CZ_BACKEND_RWKV7 && cz_cdf_par_supported((int)cz_rwkv7_vocab(s), 1) &&
+        hipMalloc((void**)&s->cdf_scratch, cz_cdf_par_scratch_bytes((int)cz_rwkv7_vocab(s), 1)) != hipSuccess) { cz_set_error("cannot allocate CDF scratch"); rc = CZ_ERR_HIP; }
     if (rc == CZ_OK && cz_dec_attn_prepare(CZ_MAX_CTX) != hipSuccess) { cz_set_error("cannot reserve LDS for decode attention"); rc = CZ_ERR_HIP; }
     if (rc == CZ_OK && cz_attention_prepare(CZ_MAX_CTX) != hipSuccess) { cz_set_error("cannot reserve LDS for attention"); rc = CZ_ERR_HIP; }
     if (rc != CZ_OK) { cz_session_close(s); return rc; }
@@ -715,7 +729,7 @@ static cz_status make_lane(cz_session* p, cz_session** out) {
     c->max_lanes = 1;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->fallback_dev, 64) != hipSuccess ||
         hipMemset(c->fallback_dev, 0, 64) != hipSuccess ||
-        (p->cdf_scratch && hipMalloc((void**)&c->cdf_scratch, cz_cdf_par_scratch_bytes(c->llama.cfg.vocab)) != hipSuccess)) {
+        (p->cdf_scratch && hipMalloc((void**)&c->cdf_scratch, cz_cdf_par_scratch_bytes(c->llama.cfg.vocab, 0)) != hipSuccess)) {
         cz_session_close(c); cz_set_error("cannot allocate a decode lane"); return CZ_ERR_HIP;
     }
     *out = c;
@@ -807,6 +821,8 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "no_graph")) s->no_graph = (int)value;
     else if (!strcmp(key, "attn_v1")) g_attn_v1 = (int)value;
     else if (!strcmp(key, "max_lanes")) s->max_lanes = (int)value;
+    else if (!strcmp(key, "probe_launch")) s->probe_launch = (int)value;
+    else if (!strcmp(key, "dec_grid_target")) g_dec_grid_target = (int)value;
     else { cz_set_error("unknown debug key %s", key); return CZ_ERR_ARG; }
     return CZ_OK;
 }
@@ -814,6 +830,9 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
 // number of rows the exact-parallel CDF kernel handed to the serial walk since the session was opened
 extern "C" long cz_debug_get(cz_session* s, const char* key) {
     if (!s || !key) return -1;
+    if (!strcmp(key, "graph_launch_cpu_us")) { unsigned long long t = s->graph_launch_cpu_ns; s->graph_launch_cpu_ns = 0; return (long)(t / 1000); }
+    if (!strcmp(key, "graph_launch_idle_us")) { unsigned long long t = s->graph_launch_idle_ns; s->graph_launch_idle_ns = 0; return (long)(t / 1000); }   // first 64 launches
+    if (!strcmp(key, "graph_launch_us")) { unsigned long long t = s->graph_launch_ns; s->graph_launch_ns = 0; return (long)(t / 1000); }   // host time inside hipGraphLaunch
     if (!strcmp(key, "cdf_fallback_rows")) {
         unsigned v = 0;
         hipStreamSynchronize(s->stream);

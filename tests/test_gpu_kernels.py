@@ -178,8 +178,33 @@ def test_exact_parallel_cdf_on_adversarial_rows(cz, czo, V):
     assert fallbacks <= 3 * 2, fallbacks
 
 
+@pytest.mark.parametrize("V", [1, 2, 300, 769, 1024, 20000, 65536])
+def test_exact_parallel_cdf_literals_mode_on_adversarial_rows(cz, czo, V):
+    """RWKV mode (floor, renormalise, mix in 256 literal entries, renormalise, running cdf: four sequential f64 chains,
+    src/main.rs:758-782, 2303-2325) through the exact-parallel kernel, on the same adversarial rows; the symbol may be a literal."""
+    rng = np.random.default_rng(V + 77)
+    logits = _adversarial_rows(V, rng)
+    rows = logits.shape[0]
+    n = V + 256
+    fallbacks = 0
+    for trial in range(4):
+        sym = rng.integers(0, n, rows).astype(np.uint32)
+        if trial == 0:
+            sym[:] = n - 1
+        if trial == 1:
+            sym[:] = 0
+        if trial == 2:
+            sym[:] = rng.integers(max(V - 2, 0), V + 3, rows)      # around the vocabulary / literal boundary
+        lo, hi, fb = _cdf_pairs(cz, logits, sym, V, 1, 0)
+        fallbacks += fb
+        for r in range(rows):
+            cdf = czo.logits_to_cdf(logits[r], "rwkv7")
+            assert (lo[r], hi[r]) == (cdf[sym[r]], cdf[sym[r] + 1]), (V, trial, r, sym[r])
+    assert fallbacks == 0, fallbacks            # the floor keeps every chain strictly positive: nothing may leave the parallel path
+
+
 @pytest.mark.parametrize("serial", [1, 0])
-@pytest.mark.parametrize("V,mode,scale", [(512, 0, 2.0), (512, 1, 2.0), (512, 0, 40.0), (3000, 0, 6.0)])
+@pytest.mark.parametrize("V,mode,scale", [(512, 0, 2.0), (512, 1, 2.0), (512, 0, 40.0), (3000, 0, 6.0), (3000, 1, 6.0)])
 def test_device_arithmetic_decoder_matches_oracle(cz, czo, V, mode, scale, serial):
     rng = np.random.default_rng(V * 3 + mode)
     steps = 300

@@ -63,6 +63,41 @@ def test_encode_pairs_and_payload_identical_to_oracle(cz, czo, tiny_pair):
     assert np.array_equal(out, ids)
 
 
+def test_real_text_ids_canz_identical_to_oracle(cz, czo, golden):
+    """BASELINE config 2 in miniature: the first 1200 token ids of the reference's own asyoulik.txt decode trace (tests/golden,
+    SmolLM2 vocabulary 49 152) through a small seeded model: the GPU `.canz` (header v2 + payload) is byte-identical to the CPU
+    oracle's, and the GPU decodes it back to the ids."""
+    import os
+    ids = np.fromfile(os.path.join(golden, "tokens_asyoulik.u16"), np.uint16).astype(np.uint32)
+    assert ids.size == 39915 and ids.max() < 49152
+    x = np.concatenate([[0], ids[:1200]]).astype(np.uint32)
+    cfg_g = cz.tiny_llama_config(vocab=49152, d_model=128, n_layers=2, n_heads=2, n_kv_heads=1, d_ffn=256)
+    cfg_o = czo.tiny_llama_config(vocab=49152, d_model=128, n_layers=2, n_heads=2, n_kv_heads=1, d_ffn=256)
+    g = cz.Session("smollm", cfg_g, seed=5, embed_std=0.05, max_streams=2)
+    o = czo.SmolLmSession(cfg_o, seed=5, embed_std=0.05)
+    payload, clo, chi, zw = o.encode_tokens(x)
+    lo, hi = g.encode_tokens(x)
+    pay, zw2 = cz.ac_encode_pairs(lo, hi)
+    assert np.array_equal(lo, clo) and np.array_equal(hi, chi) and pay == payload and zw == zw2 == 0
+    text = open(os.path.join(golden, "inputs", "asyoulik.txt"), "rb").read()
+    blobs = []
+    for mod, H in ((cz, cz.Header), (czo, czo.Header)):
+        h = H()
+        h.bos_token_id, h.token_count, h.orig_len_bytes = 0, 1200, len(text)
+        digest = mod.blake3_16(text)
+        for dst in (h.model_hash16, h.tokenizer_hash16, h.orig_hash16):
+            for i in range(16):
+                dst[i] = digest[i]
+        h.reserved_flags, h.context_window, h.vocab_size, h.reprime_interval = 512 << 16, 512, 49152, 512
+        blobs.append(mod.write_header(h, b"synthetic:5") + (pay if mod is cz else payload))
+    assert blobs[0] == blobs[1] and blobs[0][:4] == b"GTPZ"
+    hh, rep, used = cz.read_header(blobs[0])
+    assert rep == b"synthetic:5" and hh.token_count == 1200
+    out = g.decode_tokens(blobs[0][used:], 1200)
+    assert np.array_equal(out, x)
+    g.close(); o.close()
+
+
 def test_context_1024_and_small_intervals(cz, czo, tiny_pair):
     g, o = tiny_pair
     rng = np.random.default_rng(2)
