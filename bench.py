@@ -140,8 +140,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("CZ_BENCH_DIST_BACKEND", "nccl")       # "gloo": rehearsal of the N > 1 path on a one-GPU box
+        if backend == "gloo":
+            local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     import candlezip_amd as cz
     cfg = cz.tiny_llama_config() if args.tiny else cz.smollm2_135m_config()
     sess = cz.Session("smollm", cfg, seed=0x5EED, embed_std=0.02, device=local, max_streams=min(256, args.streams, args.lane_streams))
@@ -190,10 +196,11 @@ def main():
     sess.profile_enable(False)
     dominant = max(prof_all, key=lambda k: prof_all[k]["total_ms"]) if prof_all else "gemm_bf16w_f32_mfma"
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([tok], dtype=torch.float64, device="cuda")
+        c = torch.tensor([tok], dtype=torch.float64, device=dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_tok = float(c.item())
     else:

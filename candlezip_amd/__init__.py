@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcandlezip_hip.so")
+LIB_PATH = os.environ.get("CANDLEZIP_AMD_LIB") or os.path.join(_HERE, "lib", "libcandlezip_hip.so")   # override: tuning builds only
 AC_CDF_TOTAL = 1 << 30
 
 BACKEND_SMOLLM, BACKEND_RWKV7 = 0, 1

@@ -20,7 +20,7 @@
 
 #define T_PAR 1024
 #define LMAX_SMOLLM 48                 // 1024 x 48 = 49 152 symbols (SmolLM2)
-#define LMAX_RWKV 66                   // 1024 x 66 >= 65 536 + 256 symbols (RWKV World vocabulary + literal bytes)
+#define LMAX_RWKV 68                   // 1024 x 68 >= 65 536 + 256 symbols (RWKV World vocabulary + literal bytes), multiple of 4
 #define NWAVE (T_PAR / 64)
 #define POOL_SLOTS 48
 #define B_INVALID (-100000)
@@ -70,6 +70,10 @@ template <class SM> __device__ __forceinline__ double block_excl_scan(double v, 
     return base + inc - v;
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int l) {       // l uniform (v_readlane_b32 x 2)
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
 // transducer composition "f then g" on one binade grid: out.D_p = f.D_p + g.D_{p xor parity(f.D_p)}
 struct tdx { double d0, d1; int p; };      // p: bit0 = parity(d0/u), bit1 = parity(d1/u)
 __device__ __forceinline__ tdx td_compose(const tdx& f, const tdx& g) {
@@ -82,52 +86,59 @@ __device__ __forceinline__ tdx td_compose(const tdx& f, const tdx& g) {
     return h;
 }
 
+// tuning aid: block 0 / thread 0 accumulates wall_clock64 ticks (10 ns) per phase when CZ_CDF_PHASE_TIMERS is defined
+#ifdef CZ_CDF_PHASE_TIMERS
+__device__ unsigned long long g_cdf_phase[16];
+#define PH(i) do { if (blockIdx.x == 0 && tid == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_cdf_phase[i], t_ - ph_t); ph_t = t_; } } while (0)
+#else
+#define PH(i) do { } while (0)
+#endif
 // Exact left-to-right sum of the block's terms xf(k) (thread t owns terms first..first+cnt-1, k < cnt <= LMAX).
 // Returns the exact total; with want_acc_in also the exact running sum before this thread's first term.
 // csum = APPROXIMATE sum of this thread's terms (any rounding; it only feeds the binade guesses).
 template <int LMAX, typename XF>
 __device__ __forceinline__ double exact_seq_sum(XF xf, double csum, int cnt, int first, par_smem_t<LMAX>& sm, double* scratch, bool want_acc_in,
-                                                double* acc_in_out) {
+                                                double* acc_in_out, unsigned long long& ph_t) {
+    static_assert(LMAX <= 128, "the resolve holds a chunk's terms in two registers per lane");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) sm.pool_next = 0;
     const double pstart = block_excl_scan(csum, sm);            // (contains barriers: the reset above is visible afterwards)
     const double pend = pstart + csum;
+    PH(8);
     int b = B_INVALID; double d0 = 0.0, d1 = 0.0;
-    bool copy = false;
-    if (cnt == 0) b = B_EMPTY;
-    else {
-        copy = true;
-        if (pstart > 1e-290 && pend < 1e290) {
-            const int bs = expo_f64(pstart);
-            const double r0 = pow2_f64(bs), u = pow2_f64(bs - 52), r1 = r0 + u, top = pow2_f64(bs + 1);
-            double e0 = r0, e1 = r1;
-#pragma unroll
-            for (int k = 0; k < LMAX; ++k) if (k < cnt) { const double x = xf(k); e0 = e0 + x; e1 = e1 + x; }
-            if (e0 < top && e1 < top) {
-                b = bs; d0 = e0 - r0; d1 = e1 - r1;
-                // the approximate prefix is within ~n*2^-53 (< 1e-11) relative of the true one, so inside this margin the true
-                // acc is certainly in binade bs across the whole chunk and the transducer will be accepted: no copy needed
-                if (pstart > r0 * (1.0 + 1e-9) && pend < top * (1.0 - 1e-9)) copy = false;
-            }
-        }
-    }
+    // Whether this chunk must keep a copy of its terms is known BEFORE its chain runs: inside the margin below the approximate
+    // prefix (within ~n*2^-53 < 1e-11 relative of the true one) proves that the true acc stays in binade bs across the whole chunk
+    // (and then r0 + sum <= pend < top, so the transducer exists).  Every other non-empty chunk parks its terms while the chain
+    // is evaluated — one evaluation of xf per term, which matters when a term costs three f64 divisions.
+    const bool in_range = cnt > 0 && pstart > 1e-290 && pend < 1e290;
+    const int bs = in_range ? expo_f64(pstart) : 0;
+    const double r0 = pow2_f64(bs), u = pow2_f64(bs - 52), r1 = r0 + u, top = pow2_f64(bs + 1);
+    const bool copy = cnt > 0 && !(in_range && pstart > r0 * (1.0 + 1e-9) && pend < top * (1.0 - 1e-9));
     unsigned char where = 0;
+    double* park = nullptr;
     if (copy) {
         const unsigned slot = atomicAdd(&sm.pool_next, 1u);
-        if (slot < POOL_SLOTS) {
-            where = (unsigned char)(slot + 1);
-#pragma unroll
-            for (int k = 0; k < LMAX; ++k) if (k < cnt) sm.pool[slot][k] = xf(k);
-        } else {
-            where = 255;
-#pragma unroll
-            for (int k = 0; k < LMAX; ++k) if (k < cnt) scratch[first + k] = xf(k);
-        }
+        if (slot < POOL_SLOTS) { where = (unsigned char)(slot + 1); park = sm.pool[slot]; }
+        else { where = 255; park = scratch + first; }                                  // pool exhausted (rare): global copy
     }
+    if (cnt == 0) b = B_EMPTY;
+    else {
+        double e0 = r0, e1 = r1;
+#pragma unroll
+        for (int k = 0; k < LMAX; ++k)
+            if (k < cnt) {
+                const double x = xf(k);
+                e0 = e0 + x; e1 = e1 + x;
+                if (copy) park[k] = x;
+            }
+        if (in_range && e0 < top && e1 < top) { b = bs; d0 = e0 - r0; d1 = e1 - r1; }
+    }
+    PH(9);
     const bool clean = (b != B_INVALID && b != B_EMPTY && !copy);
     sm.bexp[tid] = b; sm.has_copy[tid] = where; sm.cls[tid] = clean ? 1 : 0;
     __threadfence_block();
     __syncthreads();
+    PH(10);
     // ---- segments: maximal runs of provably-clean chunks of one binade; every other non-empty chunk is a singleton
     const bool nonempty = b != B_EMPTY;
     bool head = nonempty;
@@ -172,31 +183,52 @@ __device__ __forceinline__ double exact_seq_sum(XF xf, double csum, int cnt, int
     }
     sm.sD0[tid] = v.d0; sm.sD1[tid] = v.d1; sm.sp[tid] = (unsigned char)v.p; sm.headof[tid] = (short)hidx;
     __syncthreads();
-    // ---- ordered resolve over the segments (thread 0)
-    if (tid == 0) {
+    PH(11);
+    // ---- ordered resolve over the segments (wave 0, every lane runs the same scalar walk; segment descriptors and the terms of
+    //      a dirty chunk are fetched by the lanes in parallel and fed to the chain with v_readlane, not with dependent LDS reads)
+    if (wave == 0) {
         double acc = 0.0;
-        const int L = sm.L, n = sm.n, nh = sm.nheads;
-        for (int i = 0; i < nh; ++i) {
-            const int t = sm.heads[i];
-            const int te = (i + 1 < nh ? (int)sm.heads[i + 1] : (n + L - 1) / L) - 1;     // last chunk of the segment
-            sm.segacc[t] = acc;
-            const int bj = sm.bexp[t];
-            bool done = false;
-            if (bj != B_INVALID && acc > 0.0 && expo_f64(acc) == bj) {
-                const double cand = acc + (parity_f64(acc) ? sm.sD1[te] : sm.sD0[te]);
-                if (cand < pow2_f64(bj + 1)) { acc = cand; done = true; }
+        const int L = sm.L, n = sm.n, nh = sm.nheads, nchunks = (n + L - 1) / L;
+        for (int base = 0; base < nh; base += 64) {
+            // lane j fetches everything the walk needs about segment base + j; the walk itself then reads registers only
+            const int i = base + lane;
+            int t = 0, bj = B_INVALID, wh = 0; double D0 = 0.0, D1 = 0.0;
+            if (i < nh) {
+                t = sm.heads[i];
+                const int te = (i + 1 < nh ? (int)sm.heads[i + 1] : nchunks) - 1;         // last chunk of the segment
+                bj = sm.bexp[t]; wh = sm.has_copy[t]; D0 = sm.sD0[te]; D1 = sm.sD1[te];
             }
-            if (!done) {
-                const int wh = sm.has_copy[t];
-                if (!wh) { sm.flag = 1; continue; }                  // a "provably clean" segment failed its check: serial fallback
-                const int f0 = t * L, c = n - f0 < L ? n - f0 : L;
-                if (wh != 255) { const double* src = sm.pool[wh - 1]; for (int k = 0; k < c; ++k) acc = acc + src[k]; }   // the chunk's true chain
-                else for (int k = 0; k < c; ++k) acc = acc + scratch[f0 + k];           // pool exhausted (rare): global copy
+            double myacc = 0.0;
+            const int lim = nh - base < 64 ? nh - base : 64;
+            for (int j = 0; j < lim; ++j) {
+                if (lane == j) myacc = acc;
+                const int bjj = __builtin_amdgcn_readlane(bj, j);
+                bool done = false;
+                if (bjj != B_INVALID && acc > 0.0 && expo_f64(acc) == bjj) {
+                    const double cand = acc + (parity_f64(acc) ? readlane_f64(D1, j) : readlane_f64(D0, j));
+                    if (cand < pow2_f64(bjj + 1)) { acc = cand; done = true; }
+                }
+                if (!done) {
+                    const int whj = __builtin_amdgcn_readlane(wh, j), tj = __builtin_amdgcn_readlane(t, j);
+                    if (!whj) { if (lane == 0) sm.flag = 1; continue; }   // a "provably clean" segment failed its check: serial fallback
+                    const int f0 = tj * L, c = n - f0 < L ? n - f0 : L;
+                    const double* src = whj != 255 ? sm.pool[whj - 1] : scratch + f0;     // LDS pool slot, or (pool exhausted, rare) the global copy
+                    const double x0 = lane < c ? src[lane] : 0.0;
+                    const double x1 = (LMAX > 64 && 64 + lane < c) ? src[64 + lane] : 0.0;
+                    // the chunk's true chain; lanes past the chunk hold +0.0 (acc + 0.0 == acc), so the trip count is a compile-time
+                    // constant and the v_readlane pairs are scheduled ahead of the dependent adds
+#pragma unroll
+                    for (int k = 0; k < (LMAX < 64 ? LMAX : 64); ++k) acc = acc + readlane_f64(x0, k);
+#pragma unroll
+                    for (int k = 64; k < LMAX; ++k) acc = acc + readlane_f64(x1, k - 64);
+                }
             }
+            if (i < nh) sm.segacc[t] = myacc;
         }
-        sm.total = acc;
+        if (lane == 0) sm.total = acc;
     }
     __syncthreads();
+    PH(12);
     const double total = sm.total;
     if (want_acc_in) {
         double a = 0.0;
@@ -229,7 +261,8 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = MODE ? V + 256 : V;                              // symbols of the coded alphabet
     double* scratch = scratch_all + (size_t)blockIdx.x * n;
-    const int L = (n + T_PAR - 1) / T_PAR;
+    int L = (n + T_PAR - 1) / T_PAR;
+    if (L >= 8) L = (L + 3) & ~3;                                  // chunks start on 16-B boundaries: 4 logits per load
     const int first = tid * L;
     const int cntA = first >= V ? 0 : (V - first < L ? V - first : L);       // owned vocabulary entries (terms of the chains over V)
     const int cnt = first >= n ? 0 : (n - first < L ? n - first : L);        // owned symbols (vocabulary, then literals)
@@ -244,10 +277,29 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
         }
         const float* l = logits + (size_t)row * ld;
         if (tid == 0) { sm.flag = 0; sm.L = L; sm.n = V; sm.found = (unsigned)n - 1u; sm.ok = 1; }
+        unsigned long long ph_t = 0;
+#ifdef CZ_CDF_PHASE_TIMERS
+        ph_t = wall_clock64();
+#endif
         float ef[LMAX];
         float m = -INFINITY;
+        if ((L & 3) == 0 && ((size_t)l & 15) == 0) {             // a lane's chunk is contiguous: 16-B loads (a quarter of the cache-line visits)
 #pragma unroll
-        for (int k = 0; k < LMAX; ++k) if (k < cntA) { ef[k] = l[first + k]; if (ef[k] > m) m = ef[k]; }
+            for (int k = 0; k < LMAX; k += 4) {
+                if (k + 3 < cntA) {
+                    const float4 q = *reinterpret_cast<const float4*>(l + first + k);
+                    ef[k] = q.x; ef[k + 1] = q.y; ef[k + 2] = q.z; ef[k + 3] = q.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (k + j < LMAX && k + j < cntA) ef[k + j] = l[first + k + j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < LMAX; ++k) if (k < cntA) ef[k] = l[first + k];
+        }
+#pragma unroll
+        for (int k = 0; k < LMAX; ++k) if (k < cntA && ef[k] > m) m = ef[k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { float y = __shfl_xor(m, o); m = y > m ? y : m; }
         if (lane == 0) sm.redf[wave] = m;
@@ -261,7 +313,9 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
         double csum_e = 0.0;
 #pragma unroll
         for (int k = 0; k < LMAX; ++k) if (k < cntA) csum_e += (double)ef[k];
-        const double sum = exact_seq_sum<LMAX>([&](int k) { return (double)ef[k]; }, csum_e, cntA, first, sm, scratch, false, nullptr);
+        PH(0);
+        const double sum = exact_seq_sum<LMAX>([&](int k) { return (double)ef[k]; }, csum_e, cntA, first, sm, scratch, false, nullptr, ph_t);
+        PH(1);
         bool fallback = sm.flag != 0 || !(sum > 0.0);            // sum <= 0 (uniform pdf, :794) or NaN: take the serial walk
         double acc = 0.0;
         // MODE 0: pdf term k of this thread, exactly as the reference computes it (:799): exps[i] / sum (recomputed, not stored: registers)
@@ -278,26 +332,28 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
             return sum2 > 0.0 ? x / sum2 : x;                                                                    // :779
         };
         if (MODE == 1 && !fallback) {
+            // approximate chunk sums (they only steer the binade guesses): reciprocal multiply instead of a division per term
+            const double inv_sum = 1.0 / sum;
             double cs = 0.0;
 #pragma unroll
-            for (int k = 0; k < LMAX; ++k) if (k < cntA) cs += fl(k);
-            norm = exact_seq_sum<LMAX>(fl, cs, cntA, first, sm, scratch, false, nullptr);
+            for (int k = 0; k < LMAX; ++k) if (k < cntA) { const double p = (double)ef[k] * inv_sum; cs += p > P_MIN ? p : P_MIN; }
+            norm = exact_seq_sum<LMAX>(fl, cs, cntA, first, sm, scratch, false, nullptr, ph_t);
+            PH(2);
             fallback = sm.flag != 0 || !(norm > 0.0);
             if (!fallback) {
                 if (tid == 0) sm.n = n;                          // the last two chains run over vocabulary + literals
-                double cs2 = 0.0;
-#pragma unroll
-                for (int k = 0; k < LMAX; ++k) if (k < cnt) cs2 += mix(k);
-                sum2 = exact_seq_sum<LMAX>(mix, cs2, cnt, first, sm, scratch, false, nullptr);
+                const double cs2 = cs * (scale / norm) + (double)(cnt - cntA) * lit;
+                sum2 = exact_seq_sum<LMAX>(mix, cs2, cnt, first, sm, scratch, false, nullptr, ph_t);
+                PH(3);
                 fallback = sm.flag != 0 || !(sum2 > 0.0);
                 if (!fallback) {
-                    exact_seq_sum<LMAX>(pd, cs2 / sum2, cnt, first, sm, scratch, true, &acc);
+                    exact_seq_sum<LMAX>(pd, cs2 / sum2, cnt, first, sm, scratch, true, &acc, ph_t);
                     fallback = sm.flag != 0;
                 }
             }
         }
         if (MODE == 0 && !fallback) {
-            exact_seq_sum<LMAX>(pd, csum_e / sum, cnt, first, sm, scratch, true, &acc);
+            exact_seq_sum<LMAX>(pd, csum_e / sum, cnt, first, sm, scratch, true, &acc, ph_t);
             fallback = sm.flag != 0;
         }
         if (fallback) {                                          // rare: exact serial walk by one lane
@@ -317,23 +373,28 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
             __syncthreads();
             continue;
         }
+        PH(4);
         const double acc_in = acc;
+        // Only the chunk that holds the symbol walks its terms once more (exact acc_in in hand); the other fifteen waves are done.
         if (!DECODE) {
             const uint32_t s = sym[row];
-            if (tid == 0 && s == 0) c_lo[row] = 0;
             if (tid == 0 && s >= (uint32_t)n) { c_lo[row] = 0; c_hi[row] = 0; }
+            if (cnt > 0 && s >= (uint32_t)first && s < (uint32_t)(first + cnt)) {
+                uint32_t lo = s == 0 ? 0u : quantize_u(acc_in), hi = 0;                 // cdf[first] (value when s == first)
 #pragma unroll
-            for (int k = 0; k < LMAX; ++k)
-                if (k < cnt) {
-                    acc = acc + pd(k);
-                    const uint32_t i = (uint32_t)(first + k);
-                    if (i == s || i + 1 == s) {
+                for (int k = 0; k < LMAX; ++k)
+                    if (k < cnt && (uint32_t)(first + k) <= s) {
+                        acc = acc + pd(k);
+                        const uint32_t i = (uint32_t)(first + k);
                         const uint32_t v = (i + 1 == (uint32_t)n) ? CDF_TOTAL_U : quantize_u(acc);   // cdf[n] = total forced (:822, :2321)
-                        if (i == s) c_hi[row] = v; else c_lo[row] = v;
+                        if (i + 1 == s) lo = v;
+                        if (i == s) hi = v;
                     }
-                }
+                c_lo[row] = lo; c_hi[row] = hi;
+            }
         } else {
             if (tid == 0) { bool ok; sm.value = dec_value(d, ok); sm.ok = ok ? 1 : 0; }
+            sm.bexp[tid] = cnt > 0 ? (int)quantize_u(acc_in) : (int)CDF_TOTAL_U;        // cdf[first] of every chunk (bexp is free between chains)
             __syncthreads();
             if (!sm.ok) {                                        // the reference would panic (range == 0)
                 if (tid == 0) { d.active = 0; dst[row] = d; sym_out[row] = 0; }
@@ -341,34 +402,27 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
                 continue;
             }
             const uint32_t value = sm.value;
-            // smallest index whose upper cdf bound exceeds value (== the reference's binary search, :508-514)
-            unsigned mine = 0xffffffffu;
-#pragma unroll
-            for (int k = 0; k < LMAX; ++k)
-                if (k < cnt) {
-                    acc = acc + pd(k);
-                    const uint32_t i = (uint32_t)(first + k);
-                    const uint32_t v = (i + 1 == (uint32_t)n) ? CDF_TOTAL_U : quantize_u(acc);
-                    if (v > value && mine == 0xffffffffu) mine = i;
-                }
-            if (mine != 0xffffffffu) atomicMin(&sm.found, mine);
-            __syncthreads();
-            const uint32_t s = sm.found;
-            if (s >= (uint32_t)first && s < (uint32_t)(first + cnt)) {      // owner of s provides cdf[s], cdf[s+1]
-                double a = acc_in; uint32_t lo = quantize_u(acc_in), hi = 0;
-                if (s == 0) lo = 0;
+            // the symbol = smallest index whose upper cdf bound exceeds value (== the reference's binary search, :508-514, which never
+            // runs past n - 1).  cdf[first] is monotone over the chunks, so exactly one chunk brackets value.
+            const uint32_t qstart = first == 0 ? 0u : (uint32_t)sm.bexp[tid];
+            const uint32_t qend = tid + 1 < T_PAR ? (uint32_t)sm.bexp[tid + 1] : CDF_TOTAL_U;   // the last chunk ends at the forced total
+            const bool last_chunk = cnt > 0 && first + cnt == n;
+            if (cnt > 0 && qstart <= value && (value < qend || last_chunk)) {
+                unsigned mine = 0xffffffffu;
+                uint32_t prev = qstart, my_lo = 0, my_hi = 0;
 #pragma unroll
                 for (int k = 0; k < LMAX; ++k)
                     if (k < cnt) {
-                        a = a + pd(k);
+                        acc = acc + pd(k);
                         const uint32_t i = (uint32_t)(first + k);
-                        const uint32_t v = (i + 1 == (uint32_t)n) ? CDF_TOTAL_U : quantize_u(a);
-                        if (i + 1 == s) lo = v;
-                        if (i == s) hi = v;
+                        const uint32_t v = (i + 1 == (uint32_t)n) ? CDF_TOTAL_U : quantize_u(acc);
+                        if ((v > value || i + 1 == (uint32_t)n) && mine == 0xffffffffu) { mine = i; my_lo = prev; my_hi = v; }   // cdf[i] <= value < cdf[i+1]
+                        prev = v;
                     }
-                sm.lo = lo; sm.hi = hi;
+                sm.found = mine; sm.lo = my_lo; sm.hi = my_hi;
             }
             __syncthreads();
+            const uint32_t s = sm.found;
             if (tid == 0) {
                 dec_update(d, sm.lo, sm.hi);
                 d.out_ids[step_i + 1] = s;
@@ -377,8 +431,16 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
             }
         }
         __syncthreads();
+        PH(5);
     }
 }
+#ifdef CZ_CDF_PHASE_TIMERS
+extern "C" void cz_debug_cdf_phases(unsigned long long* out16, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_cdf_phase), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_cdf_phase), z, sizeof z); }
+}
+#endif
 
 bool cz_cdf_par_supported(int vocab, int mode) { return mode == 0 ? vocab <= T_PAR * LMAX_SMOLLM : vocab + 256 <= T_PAR * LMAX_RWKV; }
 

@@ -112,7 +112,7 @@ extern "C" cz_status cz_debug_cdf_pairs(const float* logits, const uint32_t* sym
     DevMem m;
     float* dl = (float*)m.alloc((size_t)rows * V * 4);
     uint32_t *ds = (uint32_t*)m.alloc(rows * 4), *dlo = (uint32_t*)m.alloc(rows * 4), *dhi = (uint32_t*)m.alloc(rows * 4);
-    double* dscr = (!serial && cz_cdf_par_supported(V, mode)) ? (double*)m.alloc((size_t)(rows < CZ_CDF_PAR_MAX_GRID ? rows : CZ_CDF_PAR_MAX_GRID) * (V + 256) * 8) : nullptr;
+    double* dscr = (!serial && cz_cdf_par_supported(V, mode)) ? (double*)m.alloc((size_t)(rows < CZ_CDF_PAR_MAX_GRID ? rows : CZ_CDF_PAR_MAX_GRID) * (V + 256) * 16) : nullptr;
     if (!dl || !ds || !dlo || !dhi || (!serial && cz_cdf_par_supported(V, mode) && !dscr)) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
     PCHK(hipMemcpy(dl, logits, (size_t)rows * V * 4, hipMemcpyHostToDevice));
     PCHK(hipMemcpy(ds, sym, rows * 4, hipMemcpyHostToDevice));
@@ -142,7 +142,7 @@ extern "C" cz_status cz_debug_decode_symbols(const float* logits, int steps, int
     uint32_t* dsym = (uint32_t*)m.alloc(64);
     cz_dec_state* dst = (cz_dec_state*)m.alloc(sizeof(cz_dec_state));
     cz_dec_state hs;
-    double* dscr = (!serial && cz_cdf_par_supported(V, mode)) ? (double*)m.alloc((size_t)(V + 256) * 8) : nullptr;
+    double* dscr = (!serial && cz_cdf_par_supported(V, mode)) ? (double*)m.alloc((size_t)(V + 256) * 16) : nullptr;
     if (!dl || !dp || !dout || !dsym || !dst || (!serial && cz_cdf_par_supported(V, mode) && !dscr)) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
     PCHK(hipMemcpy(dl, logits, (size_t)steps * V * 4, hipMemcpyHostToDevice));
     if (len) PCHK(hipMemcpy(dp, payload, len, hipMemcpyHostToDevice));

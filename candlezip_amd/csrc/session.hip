@@ -316,11 +316,14 @@ static cz_status ensure_streams(cz_session* s, int B) {
         }
         HIPCHK(hipMalloc((void**)&s->step_seqd, sd.size() * sizeof(cz_seq_desc)));
         HIPCHK(hipMalloc((void**)&s->step_roped, rd.size() * sizeof(cz_rope_desc)));
-        HIPCHK(hipMemcpy(s->step_seqd, sd.data(), sd.size() * sizeof(cz_seq_desc), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(s->step_roped, rd.data(), rd.size() * sizeof(cz_rope_desc), hipMemcpyHostToDevice));
+        // (never the legacy stream here: another decode lane may be capturing its step graph at this moment)
+        HIPCHK(hipMemcpyAsync(s->step_seqd, sd.data(), sd.size() * sizeof(cz_seq_desc), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->step_roped, rd.data(), rd.size() * sizeof(cz_rope_desc), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
         std::vector<int> ri(s->max_streams); for (int b = 0; b < s->max_streams; ++b) ri[b] = b;
         HIPCHK(hipMalloc((void**)&s->step_rows, ri.size() * 4));
-        HIPCHK(hipMemcpy(s->step_rows, ri.data(), ri.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(s->step_rows, ri.data(), ri.size() * 4, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
         HIPCHK(hipMalloc((void**)&s->step_logits, (size_t)s->max_streams * c.vocab * 4));
         HIPCHK(hipMalloc((void**)&s->step_sym, (size_t)s->max_streams * 4));
     }
