@@ -73,6 +73,8 @@ hipError_t cz_launch_dec_gemm_qkv(hipStream_t st, const float* A, int lda, const
                                   const uint16_t* normw, float eps);
 hipError_t cz_launch_dec_gemm_swiglu(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* H, int ldh, int M, int f, int K,
                                      const uint16_t* normw, float eps);
+hipError_t cz_launch_dec_gemm_group(hipStream_t st, int nprob, const float* const* A, const int* lda, const uint16_t* const* Wd, float* const* C, const int* ldc,
+                                    const int* N, const int* K, int M);
 hipError_t cz_launch_dec_gemm_masked(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* C, int ldc, const float* R, int M, int N, int K,
                                      const unsigned char* row_mask);
 hipError_t cz_launch_dec_gemm_relusq(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* C, int ldc, int M, int N, int K);

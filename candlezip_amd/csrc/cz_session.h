@@ -77,6 +77,7 @@ void cz_rwkv7_destroy(cz_session* s);
 size_t cz_rwkv7_vocab(const cz_session* s);
 cz_status cz_rwkv7_step_host(cz_session* s, uint32_t token, float* out_logits);
 cz_status cz_rwkv7_reprime_host(cz_session* s, const uint32_t* hist, size_t n, float* out_logits);
-cz_status cz_rwkv7_encode(cz_session* s, size_t n_streams, const uint32_t* const* ids, const size_t* n, uint32_t* const* lo, uint32_t* const* hi);
+cz_status cz_rwkv7_make_lane(const cz_session* parent, cz_session* child);
+cz_status cz_rwkv7_encode_group(cz_session* s, int B, const uint32_t* const* ids, const size_t* n, uint32_t* const* lo, uint32_t* const* hi);
 cz_status cz_rwkv7_decode_group(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs, uint32_t bos,
                                 uint32_t* const* out_ids);

@@ -87,22 +87,22 @@ struct dec_gemm_args {
 
 // MT = 16-row tiles per block (1, 2, 4, 8): one load of the weight slab serves MT x 16 rows.
 template <int EPI, int NORM, int MT>
-__global__ __launch_bounds__(768) void dec_gemm_kernel(dec_gemm_args a) {
+__device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int bx, const int by) {
     extern __shared__ __attribute__((aligned(16))) float part[];       // [NW][G][2][16][17], G = min(MT, 2) row tiles per reduction round
     __shared__ float nsq[MT * 16][17];
     __shared__ float nm[MT * 16];
     constexpr int G = MT < 2 ? MT : 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    const int m0 = blockIdx.y * (MT * 16);
+    const int m0 = by * (MT * 16);
     int n0, n1;
     if (EPI == EPI_ROPE) {                       // pair (c, c+32) inside one 64-wide head; v heads: two plain tiles of the same head
-        const int head = blockIdx.x >> 1, j = blockIdx.x & 1;
+        const int head = bx >> 1, j = bx & 1;
         n0 = head * 64 + j * 16; n1 = n0 + 32;
     } else if (EPI == EPI_SWIGLU) {              // gate tile + matching up tile
-        n0 = blockIdx.x * 16; n1 = a.N / 2 + n0;
+        n0 = bx * 16; n1 = a.N / 2 + n0;
     } else {
-        n0 = blockIdx.x * 32; n1 = n0 + 16;
+        n0 = bx * 32; n1 = n0 + 16;
     }
     const int K = a.K, nch = K >> 6;
     if (NORM) {
@@ -247,6 +247,21 @@ __global__ __launch_bounds__(768) void dec_gemm_kernel(dec_gemm_args a) {
     }
 }
 
+template <int EPI, int NORM, int MT>
+__global__ __launch_bounds__(768) void dec_gemm_kernel(dec_gemm_args a) { dec_gemm_body<EPI, NORM, MT>(a, blockIdx.x, blockIdx.y); }
+
+// Several independent plain GEMMs of one decode step in ONE launch (blockIdx.z = problem): the RWKV7 time-mix needs seven
+// projections of differently mixed inputs, then four LoRA up-projections; as separate launches they cost ~7 us each for a few
+// hundred ns of work.  Blocks past a problem's own column count leave at once (uniformly, before any barrier).
+#define DEC_GROUP_MAX 8
+struct dec_gemm_group { dec_gemm_args a[DEC_GROUP_MAX]; int gx[DEC_GROUP_MAX]; };
+template <int MT>
+__global__ __launch_bounds__(768) void dec_gemm_group_kernel(dec_gemm_group g) {
+    const int z = blockIdx.z;
+    if ((int)blockIdx.x >= g.gx[z]) return;
+    dec_gemm_body<EPI_PLAIN, 0, MT>(g.a[z], blockIdx.x, blockIdx.y);
+}
+
 static int dec_nw(int K) { int nch = K / 64; nch = nch < 12 ? nch : 12; return nch < 4 ? 4 : nch; }   // >= 256 threads: one per element of a tile
 template <int EPI, int NORM, int MT>
 static hipError_t dec_gemm_launch_mt(hipStream_t st, const dec_gemm_args& a, int gx) {
@@ -292,6 +307,25 @@ hipError_t cz_launch_dec_gemm_masked(hipStream_t st, const float* A, int lda, co
     if (N % 32 || K % 64) return hipErrorInvalidValue;
     dec_gemm_args a{}; a.A = A; a.lda = lda; a.Wd = Wd; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc; a.R = R; a.row_mask = row_mask;
     return dec_gemm_launch<EPI_PLAIN>(st, a, N / 32);
+}
+// nprob plain GEMMs C_i[M][N_i] = A_i(kq) . W_i^T sharing M, one launch
+hipError_t cz_launch_dec_gemm_group(hipStream_t st, int nprob, const float* const* A, const int* lda, const uint16_t* const* Wd, float* const* C, const int* ldc,
+                                    const int* N, const int* K, int M) {
+    if (M <= 0 || nprob <= 0) return hipSuccess;
+    if (nprob > DEC_GROUP_MAX) return hipErrorInvalidValue;
+    dec_gemm_group g{};
+    int gxmax = 0, kmax = 0;
+    for (int i = 0; i < nprob; ++i) {
+        if (N[i] % 32 || K[i] % 64) return hipErrorInvalidValue;
+        dec_gemm_args& a = g.a[i];
+        a.A = A[i]; a.lda = lda[i]; a.Wd = Wd[i]; a.M = M; a.N = N[i]; a.K = K[i]; a.C = C[i]; a.ldc = ldc[i];
+        g.gx[i] = N[i] / 32;
+        gxmax = gxmax > g.gx[i] ? gxmax : g.gx[i]; kmax = kmax > K[i] ? kmax : K[i];
+    }
+    const int NW = dec_nw(kmax);
+    const size_t smem = (size_t)NW * 1 * 2 * 16 * 17 * sizeof(float);
+    hipLaunchKernelGGL((dec_gemm_group_kernel<1>), dim3(gxmax, (M + 15) / 16, nprob), dim3(64 * NW), smem, st, g);
+    return hipGetLastError();
 }
 // C (kq layout, [M][N]) = relu(A(kq) . W^T)^2
 hipError_t cz_launch_dec_gemm_relusq(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* C, int ldc, int M, int N, int K) {

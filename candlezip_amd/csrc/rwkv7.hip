@@ -392,21 +392,30 @@ static cz_status rw_step(cz_session* s, int B) {
         HIPCHK(hipGetLastError());
         const float* MX = m->mix;                                   // [6][Bc][C]: r w k v a g
         auto mixp = [&](int j) { return MX + (size_t)j * Bc * C; };
-        HIPCHK(cz_launch_dec_gemm_plain(st, mixp(0), C, y.r, m->proj + 0, ldp, nullptr, B, C, C, nullptr, 0.0f));
-        HIPCHK(cz_launch_dec_gemm_plain(st, mixp(2), C, y.k, m->proj + C, ldp, nullptr, B, C, C, nullptr, 0.0f));
-        HIPCHK(cz_launch_dec_gemm_plain(st, mixp(3), C, y.v, m->proj + 2 * C, ldp, nullptr, B, C, C, nullptr, 0.0f));
-        HIPCHK(cz_launch_dec_gemm_plain(st, mixp(1), C, y.w1, m->proj + ow, ldp, nullptr, B, c.decay_rank, C, nullptr, 0.0f));
-        HIPCHK(cz_launch_dec_gemm_plain(st, mixp(4), C, y.a1, m->proj + oa, ldp, nullptr, B, c.a_rank, C, nullptr, 0.0f));
-        HIPCHK(cz_launch_dec_gemm_plain(st, mixp(5), C, y.g1, m->proj + og, ldp, nullptr, B, c.gate_rank, C, nullptr, 0.0f));
-        if (y.has_v) HIPCHK(cz_launch_dec_gemm_plain(st, mixp(3), C, y.v1, m->proj + ov, ldp, nullptr, B, c.v_rank, C, nullptr, 0.0f));
+        {   // seven projections of the six mixed inputs in one launch: r, k, v and the LoRA down-projections w1, a1, g1 (, v1)
+            const float* A[7] = {mixp(0), mixp(2), mixp(3), mixp(1), mixp(4), mixp(5), mixp(3)};
+            const int lda[7] = {C, C, C, C, C, C, C};
+            const uint16_t* W[7] = {y.r, y.k, y.v, y.w1, y.a1, y.g1, y.v1};
+            float* Cc[7] = {m->proj + 0, m->proj + C, m->proj + 2 * C, m->proj + ow, m->proj + oa, m->proj + og, m->proj + ov};
+            const int ldc[7] = {ldp, ldp, ldp, ldp, ldp, ldp, ldp};
+            const int N[7] = {C, C, C, c.decay_rank, c.a_rank, c.gate_rank, c.v_rank};
+            const int K[7] = {C, C, C, C, C, C, C};
+            HIPCHK(cz_launch_dec_gemm_group(st, y.has_v ? 7 : 6, A, lda, W, Cc, ldc, N, K, B));
+        }
         hipLaunchKernelGGL(rw_lora_act_kernel, dim3(B), dim3(128), 0, st, m->proj, ldp, ow, oa, og, ov, c.decay_rank, c.a_rank, c.gate_rank, y.has_v ? c.v_rank : 0,
                            TW, TA, TG, TV, pw, pa, pg, pv);
         HIPCHK(hipGetLastError());
         float* L2 = m->lora2;                                        // [Bc][4][C]: w_lora, a_lin, g, nu_lin
-        HIPCHK(cz_launch_dec_gemm_plain(st, TW, pw, y.w2, L2 + 0, 4 * C, nullptr, B, C, pw, nullptr, 0.0f));
-        HIPCHK(cz_launch_dec_gemm_plain(st, TA, pa, y.a2, L2 + C, 4 * C, nullptr, B, C, pa, nullptr, 0.0f));
-        HIPCHK(cz_launch_dec_gemm_plain(st, TG, pg, y.g2, L2 + 2 * C, 4 * C, nullptr, B, C, pg, nullptr, 0.0f));
-        if (y.has_v) HIPCHK(cz_launch_dec_gemm_plain(st, TV, pv, y.v2, L2 + 3 * C, 4 * C, nullptr, B, C, pv, nullptr, 0.0f));
+        {   // the LoRA up-projections in one launch
+            const float* A[4] = {TW, TA, TG, TV};
+            const int lda[4] = {pw, pa, pg, pv};
+            const uint16_t* W[4] = {y.w2, y.a2, y.g2, y.v2};
+            float* Cc[4] = {L2 + 0, L2 + C, L2 + 2 * C, L2 + 3 * C};
+            const int ldc[4] = {4 * C, 4 * C, 4 * C, 4 * C};
+            const int N[4] = {C, C, C, C};
+            const int K[4] = {pw, pa, pg, pv};
+            HIPCHK(cz_launch_dec_gemm_group(st, y.has_v ? 4 : 3, A, lda, W, Cc, ldc, N, K, B));
+        }
         hipLaunchKernelGGL(rw_state_kernel, dim3(B, H), dim3(64), 0, st, m->proj, ldp, L2, y, l, C, S, m->v_first, m->att, m->mask, Bc);
         HIPCHK(hipGetLastError());
         HIPCHK(cz_launch_dec_gemm_plain(st, m->att, C, y.o, m->x, C, m->x, B, C, C, nullptr, 0.0f));          // x = x + att
@@ -453,11 +462,21 @@ cz_status cz_rwkv7_reprime_host(cz_session* s, const uint32_t* hist, size_t n, f
 }
 
 // ------------------------------------------------------------------ token loops, RWKV branch
-cz_status cz_rwkv7_encode(cz_session* s, size_t n_streams, const uint32_t* const* ids, const size_t* n, uint32_t* const* lo, uint32_t* const* hi) {
+// a lane shares the parent's weights and owns its recurrent state and work buffers (allocated on first use)
+cz_status cz_rwkv7_make_lane(const cz_session* parent, cz_session* child) {
+    const Rwkv7Model* pm = parent->rwkv;
+    Rwkv7Model* m = new Rwkv7Model();
+    m->cfg = pm->cfg; m->emb = pm->emb; m->head = pm->head; m->lno_w = pm->lno_w; m->lno_b = pm->lno_b; m->L = pm->L;
+    child->rwkv = m;                                               // m->allocs stays empty: cz_rwkv7_destroy frees the lane's own buffers only
+    return CZ_OK;
+}
+
+// one lock-step group of B <= max_streams streams
+cz_status cz_rwkv7_encode_group(cz_session* s, int B, const uint32_t* const* ids, const size_t* n, uint32_t* const* lo, uint32_t* const* hi) {
     Rwkv7Model* m = s->rwkv; const cz_rwkv7_config& c = m->cfg;
     const uint32_t V = (uint32_t)c.vocab;
-    for (size_t g0 = 0; g0 < n_streams; g0 += (size_t)s->max_streams) {
-        const int B = (int)std::min((size_t)s->max_streams, n_streams - g0);
+    {
+        const size_t g0 = 0;
         CZCHK(rw_ensure_streams(s, B));
         CZCHK(rw_reset(s));
         std::vector<unsigned long long> off(B), len(B); size_t total = 0, maxn = 0;

@@ -712,17 +712,6 @@ extern "C" cz_status cz_reprime_logits(cz_session* s, const uint32_t* history, s
     return CZ_OK;
 }
 
-extern "C" cz_status cz_encode_tokens_batch(cz_session* s, size_t n_streams, const uint32_t* const* ids, const size_t* n, uint32_t context,
-                                            uint32_t reprime_interval, uint32_t* const* out_c_lo, uint32_t* const* out_c_hi) {
-    if (!s || !ids || !n || !out_c_lo || !out_c_hi) { cz_set_error("cz_encode_tokens_batch: null argument"); return CZ_ERR_ARG; }
-    HIPCHK(hipSetDevice(s->device));
-    if (s->backend == CZ_BACKEND_RWKV7) return cz_rwkv7_encode(s, n_streams, ids, n, out_c_lo, out_c_hi);
-    return encode_llama(s, n_streams, ids, n, context, reprime_interval, out_c_lo, out_c_hi);
-}
-extern "C" cz_status cz_encode_tokens(cz_session* s, const uint32_t* ids, size_t n, uint32_t context, uint32_t reprime_interval,
-                                      uint32_t* out_c_lo, uint32_t* out_c_hi) {
-    return cz_encode_tokens_batch(s, 1, &ids, &n, context, reprime_interval, &out_c_lo, &out_c_hi);
-}
 // ---- decode lanes.  One lock-step group is latency-bound (about sixty small dependent kernels per token), so groups beyond
 // the first run concurrently on sessions of their own (stream, KV cache, work buffers, step graph) that share the weights.
 static cz_status make_lane(cz_session* p, cz_session** out) {
@@ -730,16 +719,19 @@ static cz_status make_lane(cz_session* p, cz_session** out) {
     c->is_lane = true; c->backend = p->backend; c->device = p->device; c->seed = p->seed; c->max_streams = p->max_streams;
     c->llama = p->llama;                                   // shallow: same device tensors
     c->max_lanes = 1;
+    const bool rw = p->backend == CZ_BACKEND_RWKV7;
+    if (rw && cz_rwkv7_make_lane(p, c) != CZ_OK) { cz_session_close(c); return CZ_ERR_HIP; }
+    const size_t scratch = rw ? cz_cdf_par_scratch_bytes((int)cz_rwkv7_vocab(p), 1) : cz_cdf_par_scratch_bytes(c->llama.cfg.vocab, 0);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->fallback_dev, 64) != hipSuccess ||
-        hipMemset(c->fallback_dev, 0, 64) != hipSuccess ||
-        (p->cdf_scratch && hipMalloc((void**)&c->cdf_scratch, cz_cdf_par_scratch_bytes(c->llama.cfg.vocab, 0)) != hipSuccess)) {
-        cz_session_close(c); cz_set_error("cannot allocate a decode lane"); return CZ_ERR_HIP;
+        hipMemset(c->fallback_dev, 0, 64) != hipSuccess || (p->cdf_scratch && hipMalloc((void**)&c->cdf_scratch, scratch) != hipSuccess)) {
+        cz_session_close(c); cz_set_error("cannot allocate a lane"); return CZ_ERR_HIP;
     }
     *out = c;
     return CZ_OK;
 }
-static cz_status decode_llama_lanes(cz_session* s, size_t n_streams, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs,
-                                    uint32_t context_window, uint32_t R, uint32_t bos, uint32_t* const* out_ids) {
+// run `n_streams` streams as groups of <= max_streams on up to max_lanes lanes; group(ls, off, count) processes streams [off, off + count)
+template <class GroupFn>
+static cz_status run_on_lanes(cz_session* s, size_t n_streams, GroupFn group) {
     const size_t cap = (size_t)s->max_streams;
     const size_t G = (n_streams + cap - 1) / cap;
     // groups of near-equal size, group g = streams [off[g], off[g+1])
@@ -754,7 +746,7 @@ static cz_status decode_llama_lanes(cz_session* s, size_t n_streams, const uint8
         if (l) { ls->serial_cdf = s->serial_cdf; ls->decode_v1 = s->decode_v1; ls->no_graph = s->no_graph; ls->force_big_gemm = s->force_big_gemm;
                  ls->max_batch_rows = s->max_batch_rows; ls->logit_batch_rows = s->logit_batch_rows; }
         for (size_t g = l; g < G && rc[l] == CZ_OK; g += L) {
-            rc[l] = decode_llama_group(ls, (int)(off[g + 1] - off[g]), payloads + off[g], lens + off[g], tcs + off[g], context_window, R, bos, out_ids + off[g]);
+            rc[l] = group(ls, off[g], off[g + 1] - off[g]);
             if (rc[l] != CZ_OK) msg[l] = cz_last_error();
         }
     };
@@ -766,18 +758,33 @@ static cz_status decode_llama_lanes(cz_session* s, size_t n_streams, const uint8
     return CZ_OK;
 }
 
+extern "C" cz_status cz_encode_tokens_batch(cz_session* s, size_t n_streams, const uint32_t* const* ids, const size_t* n, uint32_t context,
+                                            uint32_t reprime_interval, uint32_t* const* out_c_lo, uint32_t* const* out_c_hi) {
+    if (!s || !ids || !n || !out_c_lo || !out_c_hi) { cz_set_error("cz_encode_tokens_batch: null argument"); return CZ_ERR_ARG; }
+    HIPCHK(hipSetDevice(s->device));
+    if (s->backend == CZ_BACKEND_RWKV7) {                  // RWKV has no re-prime: encode walks the recurrence in lock-step too, one group per lane
+        if (n_streams == 0) return CZ_OK;
+        return run_on_lanes(s, n_streams, [&](cz_session* ls, size_t o, size_t cnt) {
+            return cz_rwkv7_encode_group(ls, (int)cnt, ids + o, n + o, out_c_lo + o, out_c_hi + o);
+        });
+    }
+    return encode_llama(s, n_streams, ids, n, context, reprime_interval, out_c_lo, out_c_hi);
+}
+extern "C" cz_status cz_encode_tokens(cz_session* s, const uint32_t* ids, size_t n, uint32_t context, uint32_t reprime_interval,
+                                      uint32_t* out_c_lo, uint32_t* out_c_hi) {
+    return cz_encode_tokens_batch(s, 1, &ids, &n, context, reprime_interval, &out_c_lo, &out_c_hi);
+}
 extern "C" cz_status cz_decode_tokens_batch(cz_session* s, size_t n_streams, const uint8_t* const* payloads, const size_t* lens,
                                             const size_t* token_counts, uint32_t context_window, uint32_t reprime_interval, uint32_t bos,
                                             uint32_t* const* out_ids) {
     if (!s || !payloads || !lens || !token_counts || !out_ids) { cz_set_error("cz_decode_tokens_batch: null argument"); return CZ_ERR_ARG; }
     HIPCHK(hipSetDevice(s->device));
     if (n_streams == 0) return CZ_OK;
-    if (s->backend != CZ_BACKEND_RWKV7) return decode_llama_lanes(s, n_streams, payloads, lens, token_counts, context_window, reprime_interval, bos, out_ids);
-    for (size_t g = 0; g < n_streams; g += (size_t)s->max_streams) {
-        const int B = (int)std::min((size_t)s->max_streams, n_streams - g);
-        CZCHK(cz_rwkv7_decode_group(s, B, payloads + g, lens + g, token_counts + g, bos, out_ids + g));
-    }
-    return CZ_OK;
+    const bool rw = s->backend == CZ_BACKEND_RWKV7;
+    return run_on_lanes(s, n_streams, [&](cz_session* ls, size_t o, size_t cnt) {
+        return rw ? cz_rwkv7_decode_group(ls, (int)cnt, payloads + o, lens + o, token_counts + o, bos, out_ids + o)
+                  : decode_llama_group(ls, (int)cnt, payloads + o, lens + o, token_counts + o, context_window, reprime_interval, bos, out_ids + o);
+    });
 }
 extern "C" cz_status cz_decode_tokens(cz_session* s, const uint8_t* payload, size_t len, size_t token_count, uint32_t context_window,
                                       uint32_t reprime_interval, uint32_t bos, uint32_t* out_ids) {

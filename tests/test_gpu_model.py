@@ -250,6 +250,30 @@ def test_rwkv7_encode_decode_bitexact_with_literals(cz, czo, rwkv_pair):
         assert np.array_equal(out, s)
 
 
+def test_rwkv7_lanes_match_single_group(cz, czo, rwkv_pair):
+    """more streams than one lock-step group: RWKV encode AND decode run the groups concurrently on lanes (shared weights, own
+    recurrent state); pairs, payloads and ids must equal the oracle's stream by stream, whatever the lane count"""
+    g0, o = rwkv_pair
+    rng = np.random.default_rng(5)
+    lens = [90, 31, 64, 1, 77, 50, 0, 12, 83]
+    streams = [np.concatenate([[0], rng.integers(0, 512 + 256, n)]).astype(np.uint32) for n in lens]     # literals included
+    refs = [o.encode_tokens(s) for s in streams]
+    for lanes in (1, 3):
+        g = cz.Session("rwkv7", cz.tiny_rwkv7_config(), seed=9, embed_std=0.05, max_streams=2)             # 9 streams -> 5 groups
+        g.debug_set("max_lanes", lanes)
+        pairs = g.encode_tokens_batch(streams)
+        pays = []
+        for (lo, hi), (ref_p, clo, chi, zw) in zip(pairs, refs):
+            assert np.array_equal(lo, clo) and np.array_equal(hi, chi), lanes
+            pays.append(cz.ac_encode_pairs(lo, hi)[0])
+            assert pays[-1] == ref_p
+        outs = g.decode_tokens_batch(pays, [s.size - 1 for s in streams])
+        for s_, out in zip(streams, outs):
+            assert np.array_equal(out, s_), lanes
+        assert g.debug_get("cdf_fallback_rows") == 0
+        g.close()
+
+
 def test_rwkv7_0b1_shape_bitexact(cz, czo):
     """RWKV7-0.1B shape (C 768, 12 layers, 12 heads x 64, ffn 3072, vocab 65536), synthetic weights"""
     g = cz.Session("rwkv7", cz.rwkv7_0b1_config(), seed=3, embed_std=0.02, max_streams=2)

@@ -9,7 +9,9 @@ import candlezip_amd as cz
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 cfg = cz.rwkv7_0b1_config()
-s = cz.Session("rwkv7", cfg, seed=0x5EED, embed_std=0.02, max_streams=B)
+LANE = int(sys.argv[3]) if len(sys.argv) > 3 else B
+s = cz.Session("rwkv7", cfg, seed=0x5EED, embed_std=0.02, max_streams=min(B, LANE))
+s.debug_set("max_lanes", int(sys.argv[4]) if len(sys.argv) > 4 else 4)
 rng = np.random.default_rng(1)
 streams = [np.concatenate([[0], rng.integers(0, cfg.vocab, T)]).astype(np.uint32) for _ in range(B)]
 for rep in range(2):                       # first pass warms up
