@@ -39,7 +39,8 @@ hipError_t cz_attention_prepare(int max_nk);
 // logits -> coder interval of `sym` (encode) ; mode 0 = smollm (softmax_pdf), 1 = rwkv7 (floor + 256 literals)
 // (exact-parallel kernel when supported, else the serial walk; fallback_count (optional, device) counts rows that fell back)
 hipError_t cz_launch_cdf_pairs(hipStream_t st, const float* logits, int ld, const uint32_t* sym, uint32_t* c_lo, uint32_t* c_hi,
-                               int rows, int vocab, int mode, unsigned* fallback_count, double* scratch);
+                               int rows, int vocab, int mode, unsigned* fallback_count, double* scratch,
+                               const unsigned long long* out_step_dev = nullptr);   // non-null: pairs go to c_lo/c_hi + *out_step_dev * rows
 #define CZ_CDF_PAR_MAX_GRID 1024
 size_t cz_cdf_par_scratch_bytes(int vocab, int mode);     // the `scratch` the exact-parallel CDF launchers need (owned by the session)
 hipError_t cz_launch_cdf_pairs_serial(hipStream_t st, const float* logits, int ld, const uint32_t* sym, uint32_t* c_lo, uint32_t* c_hi,

@@ -200,6 +200,36 @@ __global__ __launch_bounds__(256, 1) void attention_v2_kernel(const float* __res
         for (int t = 0; t < 16; ++t) { const float v = qp[4 * t]; qreg[rt][t] = valid ? v : 0.0f; }
     }
     f32x4 S[NI][REP];
+    // K / V chunk loads: one block per CU and one wave per SIMD leave nothing else to hide a miss behind, so the NEXT chunk's four
+    // 16-B pieces per thread are fetched into registers while the current chunk's MFMAs run
+    auto load_k = [&](int c, f32x4* out) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int key = (tid >> 4) + 16 * p, q4 = tid & 15;
+            const int j = c * 64 + key;
+            const int jj = j < nk_blk ? j : nk_blk - 1;               // clamp (never a conditional load), zero afterwards
+            f32x4 v;
+            if (sd.kt_stride) {
+                const float* kp = sd.k + (size_t)(kvh * 64 + q4 * 4) * sd.kt_stride + jj;
+                v = f32x4{kp[0], kp[sd.kt_stride], kp[2 * (size_t)sd.kt_stride], kp[3 * (size_t)sd.kt_stride]};
+            } else v = *reinterpret_cast<const f32x4*>(sd.k + (size_t)jj * sd.kv_stride + kvh * 64 + q4 * 4);
+            if (j >= nk_blk) v = f32x4{0, 0, 0, 0};
+            out[p] = v;
+        }
+    };
+    auto load_v = [&](int c, f32x4* out) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int key = (tid >> 4) + 16 * p, q4 = tid & 15;
+            const int j = c * 64 + key;
+            const int jj = j < nk_blk ? j : nk_blk - 1;
+            f32x4 v = *reinterpret_cast<const f32x4*>(sd.v + (size_t)jj * sd.kv_stride + kvh * 64 + q4 * 4);
+            if (j >= nk_blk) v = f32x4{0, 0, 0, 0};
+            out[p] = v;
+        }
+    };
+    f32x4 pre[4];
+    load_k(0, pre);
     // ---- phase 1: scores
 #pragma unroll
     for (int c = 0; c < NI; ++c) {
@@ -207,19 +237,9 @@ __global__ __launch_bounds__(256, 1) void attention_v2_kernel(const float* __res
         for (int rt = 0; rt < REP; ++rt) S[c][rt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         if (c < nch) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int key = (tid >> 4) + 16 * p, q4 = tid & 15;
-                const int j = c * 64 + key;
-                const int jj = j < nk_blk ? j : nk_blk - 1;               // clamp (never a conditional load), zero afterwards
-                f32x4 v;
-                if (sd.kt_stride) {
-                    const float* kp = sd.k + (size_t)(kvh * 64 + q4 * 4) * sd.kt_stride + jj;
-                    v = f32x4{kp[0], kp[sd.kt_stride], kp[2 * (size_t)sd.kt_stride], kp[3 * (size_t)sd.kt_stride]};
-                } else v = *reinterpret_cast<const f32x4*>(sd.k + (size_t)jj * sd.kv_stride + kvh * 64 + q4 * 4);
-                if (j >= nk_blk) v = f32x4{0, 0, 0, 0};
-                *reinterpret_cast<f32x4*>(stage + key * V2_KS + q4 * 4) = v;
-            }
+            for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(stage + ((tid >> 4) + 16 * p) * V2_KS + (tid & 15) * 4) = pre[p];
             __syncthreads();
+            if (c + 1 < nch) load_k(c + 1, pre);                       // in flight during the MFMAs below
             float kb[16];
             const float* kbp = stage + (wave * 16 + li) * V2_KS + lg;
 #pragma unroll
@@ -241,6 +261,7 @@ __global__ __launch_bounds__(256, 1) void attention_v2_kernel(const float* __res
             __syncthreads();
         }
     }
+    load_v(0, pre);                                                    // first V chunk: in flight during the softmax phases
     // ---- phase 2: row max (exact in any order)
     float gmax[REP][4];
 #pragma unroll
@@ -315,15 +336,9 @@ __global__ __launch_bounds__(256, 1) void attention_v2_kernel(const float* __res
                     Et[(rt * 16 + qr) * V2_KS + wave * 16 + li] = qr < rows_here ? S[c][rt][r] / rs[rt][r] : 0.0f;
                 }
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int key = (tid >> 4) + 16 * p, q4 = tid & 15;
-                const int j = c * 64 + key;
-                const int jj = j < nk_blk ? j : nk_blk - 1;
-                f32x4 v = *reinterpret_cast<const f32x4*>(sd.v + (size_t)jj * sd.kv_stride + kvh * 64 + q4 * 4);
-                if (j >= nk_blk) v = f32x4{0, 0, 0, 0};
-                *reinterpret_cast<f32x4*>(stage + key * V2_VS + q4 * 4) = v;
-            }
+            for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(stage + ((tid >> 4) + 16 * p) * V2_VS + (tid & 15) * 4) = pre[p];
             __syncthreads();
+            if (c + 1 < nch) load_v(c + 1, pre);
             float vb[16];
             const float* vbp = stage + lg * V2_VS + wave * 16 + li;          // B[k = 4t + lg][j = li] = V[key][col]
 #pragma unroll

@@ -258,6 +258,7 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
                                                         const unsigned long long* __restrict__ step_dev) {
     __shared__ par_smem_t<LMAX> sm;
     if (DECODE && step_dev) step_i = *step_dev;
+    if (!DECODE && step_dev) { c_lo += *step_dev * (unsigned long long)rows; c_hi += *step_dev * (unsigned long long)rows; }   // lock-step encode under graph replay
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = MODE ? V + 256 : V;                              // symbols of the coded alphabet
     double* scratch = scratch_all + (size_t)blockIdx.x * n;
@@ -445,17 +446,17 @@ extern "C" void cz_debug_cdf_phases(unsigned long long* out16, int reset) {
 bool cz_cdf_par_supported(int vocab, int mode) { return mode == 0 ? vocab <= T_PAR * LMAX_SMOLLM : vocab + 256 <= T_PAR * LMAX_RWKV; }
 
 hipError_t cz_launch_cdf_pairs(hipStream_t st, const float* logits, int ld, const uint32_t* sym, uint32_t* c_lo, uint32_t* c_hi,
-                               int rows, int vocab, int mode, unsigned* fallback_count, double* g_scratch) {
+                               int rows, int vocab, int mode, unsigned* fallback_count, double* g_scratch, const unsigned long long* out_step_dev) {
     if (rows <= 0) return hipSuccess;
-    if (!cz_cdf_par_supported(vocab, mode)) return cz_launch_cdf_pairs_serial(st, logits, ld, sym, c_lo, c_hi, rows, vocab, mode);
+    if (!cz_cdf_par_supported(vocab, mode)) return out_step_dev ? hipErrorInvalidValue : cz_launch_cdf_pairs_serial(st, logits, ld, sym, c_lo, c_hi, rows, vocab, mode);
     if (!g_scratch) return hipErrorInvalidValue;
     const int grid = rows < CZ_CDF_PAR_MAX_GRID ? rows : CZ_CDF_PAR_MAX_GRID;
     if (mode == 0)
         hipLaunchKernelGGL((cdf_par_kernel<0, 0, LMAX_SMOLLM>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, c_lo, c_hi, g_scratch, nullptr, nullptr,
-                           0ull, fallback_count, nullptr);
+                           0ull, fallback_count, out_step_dev);
     else
         hipLaunchKernelGGL((cdf_par_kernel<0, 1, LMAX_RWKV>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, c_lo, c_hi, g_scratch, nullptr, nullptr,
-                           0ull, fallback_count, nullptr);
+                           0ull, fallback_count, out_step_dev);
     return hipGetLastError();
 }
 hipError_t cz_launch_decode_symbol(hipStream_t st, const float* logits, int ld, cz_dec_state* st_arr, uint32_t* sym_out, int nstreams,

@@ -52,6 +52,9 @@ struct Rwkv7Model {
     float* logits = nullptr;
     uint32_t *tok = nullptr, *sym = nullptr; unsigned char* mask = nullptr;
     size_t index_pos = 0;
+    // lock-step loops under hipGraph replay: one executable graph per loop kind, per-iteration scalars in HBM (step_dev)
+    struct Graph { hipGraph_t g = nullptr; hipGraphExec_t e = nullptr; int B = 0; unsigned long long gen = ~0ull; } genc, gdec;
+    unsigned long long* step_dev = nullptr;
 };
 
 // ------------------------------------------------------------------ kernels
@@ -214,23 +217,27 @@ __global__ __launch_bounds__(64) void rw_state_kernel(const float* __restrict__ 
 }
 
 __global__ void rw_pick_kernel(const uint32_t* __restrict__ ids, const unsigned long long* __restrict__ off, const unsigned long long* __restrict__ n,
-                               unsigned long long i, uint32_t V, uint32_t* __restrict__ tok, uint32_t* __restrict__ sym, unsigned char* __restrict__ mask, int B) {
+                               unsigned long long i, uint32_t V, uint32_t* __restrict__ tok, uint32_t* __restrict__ sym, unsigned char* __restrict__ mask, int B,
+                               const unsigned long long* __restrict__ step_dev) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    if (step_dev) i = *step_dev;
     const unsigned long long nb = n[b];
     uint32_t t = 0, s = 0; unsigned char m = 0;
     if (i + 1 < nb) { t = ids[off[b] + i]; s = ids[off[b] + i + 1]; m = (i == 0 || t < V) ? 1 : 0; }     // literal symbols do not step the model (:2347)
     tok[b] = t < V ? t : 0; sym[b] = s; mask[b] = m;
 }
 __global__ void rw_mask_from_sym_kernel(const cz_dec_state* __restrict__ st, const uint32_t* __restrict__ sym, uint32_t V, uint32_t* __restrict__ tok,
-                                        unsigned char* __restrict__ mask, int B, unsigned long long i) {
+                                        unsigned char* __restrict__ mask, int B, unsigned long long i, const unsigned long long* __restrict__ step_dev) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    if (step_dev) i = *step_dev;
     const bool act = st[b].active && i < st[b].token_count;
     const uint32_t s = sym[b];
     mask[b] = (act && s < V) ? 1 : 0;                                                                       // :2832
     tok[b] = s < V ? s : 0;
 }
+__global__ void rw_counter_kernel(unsigned long long* c, int inc) { if (inc) *c += 1ull; else *c = 0ull; }
 __global__ void rw_fill_kernel(uint32_t* tok, unsigned char* mask, uint32_t t, int B) { int b = blockIdx.x * blockDim.x + threadIdx.x; if (b < B) { tok[b] = t; mask[b] = 1; } }
 __global__ void rw_init_out_kernel(cz_dec_state* st, int n, uint32_t bos) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) st[i].out_ids[0] = bos; }
 
@@ -340,8 +347,14 @@ cz_status cz_rwkv7_build(cz_session* s, const cz_model_desc* desc) {
     HIPCHK(hipStreamSynchronize(s->stream));
     return CZ_OK;
 }
+static void rw_graph_destroy(Rwkv7Model::Graph& G) {
+    if (G.e) { hipGraphExecDestroy(G.e); G.e = nullptr; }
+    if (G.g) { hipGraphDestroy(G.g); G.g = nullptr; }
+    G.B = 0; G.gen = ~0ull;
+}
 void cz_rwkv7_destroy(cz_session* s) {
     if (!s->rwkv) return;
+    rw_graph_destroy(s->rwkv->genc); rw_graph_destroy(s->rwkv->gdec);
     for (auto p : s->rwkv->allocs) { hipError_t e = hipFree(p); (void)e; }
     delete s->rwkv; s->rwkv = nullptr;
 }
@@ -360,6 +373,7 @@ static cz_status rw_ensure_streams(cz_session* s, int B) {
     CZCHK(rw_alloc(m, (void**)&m->lora2, (size_t)Bc * 4 * C * 4)); CZCHK(rw_alloc(m, (void**)&m->att, (size_t)Bc * C * 4));
     CZCHK(rw_alloc(m, (void**)&m->ffk, (size_t)Bc * c.d_ffn * 4)); CZCHK(rw_alloc(m, (void**)&m->xn, (size_t)Bc * C * 4));
     CZCHK(rw_alloc(m, (void**)&m->logits, (size_t)Bc * c.vocab * 4));
+    CZCHK(rw_alloc(m, (void**)&m->step_dev, 16));
     CZCHK(rw_alloc(m, (void**)&m->tok, (size_t)Bc * 4)); CZCHK(rw_alloc(m, (void**)&m->sym, (size_t)Bc * 4)); CZCHK(rw_alloc(m, (void**)&m->mask, (size_t)Bc));
     m->B = Bc;
     return CZ_OK;
@@ -462,6 +476,29 @@ cz_status cz_rwkv7_reprime_host(cz_session* s, const uint32_t* hist, size_t n, f
 }
 
 // ------------------------------------------------------------------ token loops, RWKV branch
+// capture one iteration of a lock-step loop (`body` enqueues it on s->stream).  Every buffer the RWKV step touches is allocated
+// once (rw_ensure_streams), so only the session's DevBufs can move: s->devbuf_gen is part of the key.
+template <class F>
+static cz_status rw_graph_build(cz_session* s, Rwkv7Model::Graph& G, int B, F body) {
+    rw_graph_destroy(G);
+    const bool prof = s->prof_on; s->prof_on = false;            // no events inside a captured region
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    const cz_status rc = body();
+    hipGraph_t g = nullptr;
+    const hipError_t e2 = hipStreamEndCapture(s->stream, &g);
+    s->prof_on = prof;
+    if (rc != CZ_OK || e2 != hipSuccess || !g) {
+        if (g) hipGraphDestroy(g);
+        if (rc == CZ_OK) cz_set_error("hipGraph capture of the RWKV step failed (%s)", hipGetErrorString(e2));
+        return rc != CZ_OK ? rc : CZ_ERR_HIP;
+    }
+    G.g = g;
+    HIPCHK(hipGraphInstantiate(&G.e, G.g, nullptr, nullptr, 0));
+    G.B = B; G.gen = s->devbuf_gen;
+    return CZ_OK;
+}
+
 // a lane shares the parent's weights and owns its recurrent state and work buffers (allocated on first use)
 cz_status cz_rwkv7_make_lane(const cz_session* parent, cz_session* child) {
     const Rwkv7Model* pm = parent->rwkv;
@@ -494,13 +531,29 @@ cz_status cz_rwkv7_encode_group(cz_session* s, int B, const uint32_t* const* ids
         HIPCHK(hipMemcpyAsync(s->tok.p, flat.data(), total * 4, hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipMemcpyAsync(s->seqd.p, off.data(), B * 8, hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipMemcpyAsync(s->roped.p, len.data(), B * 8, hipMemcpyHostToDevice, s->stream));
-        for (size_t i = 0; i + 1 < maxn; ++i) {
+        const bool use_graph = !s->no_graph && !s->prof_on && cz_cdf_par_supported(c.vocab, 1);
+        auto iteration = [&](unsigned long long i, const unsigned long long* step_dev) -> cz_status {
             hipLaunchKernelGGL(rw_pick_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, (const uint32_t*)s->tok.p, (const unsigned long long*)s->seqd.p,
-                               (const unsigned long long*)s->roped.p, (unsigned long long)i, V, m->tok, m->sym, m->mask, B);
+                               (const unsigned long long*)s->roped.p, i, V, m->tok, m->sym, m->mask, B, step_dev);
             CZCHK(rw_step(s, B));
             s->prof_begin(PK_CDF);
-            HIPCHK(cz_launch_cdf_pairs(s->stream, m->logits, c.vocab, m->sym, (uint32_t*)s->clo.p + i * B, (uint32_t*)s->chi.p + i * B, B, c.vocab, 1, s->fallback_dev, s->cdf_scratch));
+            HIPCHK(cz_launch_cdf_pairs(s->stream, m->logits, c.vocab, m->sym, (uint32_t*)s->clo.p + (step_dev ? 0 : i * B), (uint32_t*)s->chi.p + (step_dev ? 0 : i * B), B,
+                                       c.vocab, 1, s->fallback_dev, s->cdf_scratch, step_dev));
             s->prof_end(0, (double)B * c.vocab * 4);
+            return CZ_OK;
+        };
+        if (use_graph) {
+            if (!m->genc.e || m->genc.B != B || m->genc.gen != s->devbuf_gen)
+                CZCHK(rw_graph_build(s, m->genc, B, [&]() -> cz_status {
+                    CZCHK(iteration(0, m->step_dev));
+                    hipLaunchKernelGGL(rw_counter_kernel, dim3(1), dim3(1), 0, s->stream, m->step_dev, 1);
+                    return CZ_OK;
+                }));
+            hipLaunchKernelGGL(rw_counter_kernel, dim3(1), dim3(1), 0, s->stream, m->step_dev, 0);
+        }
+        for (size_t i = 0; i + 1 < maxn; ++i) {
+            if (use_graph) HIPCHK(hipGraphLaunch(m->genc.e, s->stream));
+            else CZCHK(iteration((unsigned long long)i, nullptr));
         }
         std::vector<uint32_t> hlo(npairs), hhi(npairs);
         if (npairs) {
@@ -541,14 +594,29 @@ cz_status cz_rwkv7_decode_group(cz_session* s, int B, const uint8_t* const* payl
     hipLaunchKernelGGL(rw_fill_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, m->tok, m->mask, bos, B);
     hipLaunchKernelGGL(rw_fill_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, m->sym, m->mask, bos, B);
     CZCHK(rw_step(s, B));                                            // step(bos) (src/main.rs:2485 equivalent for rwkv)
-    for (size_t i = 0; i < max_tc; ++i) {
+    const bool use_graph = !s->no_graph && !s->prof_on && cz_cdf_par_supported(c.vocab, 1);
+    auto iteration = [&](unsigned long long i, const unsigned long long* step_dev, bool step_after) -> cz_status {
         s->prof_begin(PK_DECODE);
-        HIPCHK(cz_launch_decode_symbol(s->stream, m->logits, c.vocab, dst, m->sym, B, c.vocab, 1, (unsigned long long)i, s->fallback_dev, nullptr, s->cdf_scratch));
+        HIPCHK(cz_launch_decode_symbol(s->stream, m->logits, c.vocab, dst, m->sym, B, c.vocab, 1, i, s->fallback_dev, step_dev, s->cdf_scratch));
         s->prof_end(0, (double)B * c.vocab * 4);
-        if (i + 1 < max_tc) {
-            hipLaunchKernelGGL(rw_mask_from_sym_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, dst, m->sym, V, m->tok, m->mask, B, (unsigned long long)i);
+        if (step_after) {
+            hipLaunchKernelGGL(rw_mask_from_sym_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, dst, m->sym, V, m->tok, m->mask, B, i, step_dev);
             CZCHK(rw_step(s, B));
         }
+        return CZ_OK;
+    };
+    if (use_graph) {
+        if (!m->gdec.e || m->gdec.B != B || m->gdec.gen != s->devbuf_gen)
+            CZCHK(rw_graph_build(s, m->gdec, B, [&]() -> cz_status {
+                CZCHK(iteration(0, m->step_dev, true));              // (the step after the last symbol is harmless: its logits are never read)
+                hipLaunchKernelGGL(rw_counter_kernel, dim3(1), dim3(1), 0, s->stream, m->step_dev, 1);
+                return CZ_OK;
+            }));
+        hipLaunchKernelGGL(rw_counter_kernel, dim3(1), dim3(1), 0, s->stream, m->step_dev, 0);
+    }
+    for (size_t i = 0; i < max_tc; ++i) {
+        if (use_graph) HIPCHK(hipGraphLaunch(m->gdec.e, s->stream));
+        else CZCHK(iteration((unsigned long long)i, nullptr, i + 1 < max_tc));
     }
     std::vector<uint32_t> all(ids_total);
     HIPCHK(hipMemcpyAsync(all.data(), s->outids.p, ids_total * 4, hipMemcpyDeviceToHost, s->stream));

@@ -258,9 +258,10 @@ def test_rwkv7_lanes_match_single_group(cz, czo, rwkv_pair):
     lens = [90, 31, 64, 1, 77, 50, 0, 12, 83]
     streams = [np.concatenate([[0], rng.integers(0, 512 + 256, n)]).astype(np.uint32) for n in lens]     # literals included
     refs = [o.encode_tokens(s) for s in streams]
-    for lanes in (1, 3):
+    for lanes, no_graph in ((1, 0), (3, 0), (2, 1)):                                                       # hipGraph replay vs eager launches
         g = cz.Session("rwkv7", cz.tiny_rwkv7_config(), seed=9, embed_std=0.05, max_streams=2)             # 9 streams -> 5 groups
         g.debug_set("max_lanes", lanes)
+        g.debug_set("no_graph", no_graph)
         pairs = g.encode_tokens_batch(streams)
         pays = []
         for (lo, hi), (ref_p, clo, chi, zw) in zip(pairs, refs):
