@@ -72,7 +72,8 @@ EXPORTS = [  # every symbol include/candlezip.h declares
     "cz_reprime_logits", "cz_encode_tokens", "cz_encode_tokens_batch", "cz_decode_tokens", "cz_decode_tokens_batch",
     "cz_ac_encode_pairs", "cz_free", "cz_write_header_v2", "cz_read_header_v2", "cz_flags_pack", "cz_skip_gate_section",
     "cz_blake3_bytes_bin16", "cz_blake3_file_bin16", "cz_blake3_files_bin16", "cz_rwkv_tokenizer_open",
-    "cz_rwkv_tokenizer_close", "cz_rwkv_plan_symbols", "cz_rwkv_detok", "cz_last_error", "cz_profile_enable",
+    "cz_rwkv_tokenizer_close", "cz_rwkv_plan_symbols", "cz_rwkv_detok", "cz_bpe_tokenizer_open", "cz_bpe_tokenizer_close",
+    "cz_bpe_vocab_size", "cz_bpe_encode", "cz_bpe_decode", "cz_last_error", "cz_profile_enable",
     "cz_profile_read", "cz_synchronize",
 ]
 
@@ -106,6 +107,9 @@ def lib():
         "cz_blake3_bytes_bin16": (None, [vp, sz, vp]), "cz_blake3_file_bin16": (C.c_int, [C.c_char_p, vp]),
         "cz_blake3_files_bin16": (C.c_int, [C.POINTER(C.c_char_p), sz, vp]),
         "cz_last_error": (C.c_char_p, []),
+        "cz_bpe_tokenizer_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]), "cz_bpe_tokenizer_close": (None, [vp]), "cz_bpe_vocab_size": (sz, [vp]),
+        "cz_bpe_encode": (C.c_int, [vp, vp, sz, C.POINTER(vp), C.POINTER(sz)]),
+        "cz_bpe_decode": (C.c_int, [vp, vp, sz, C.c_int, C.POINTER(vp), C.POINTER(sz)]),
         "cz_profile_enable": (C.c_int, [vp, C.c_int]), "cz_profile_read": (C.c_int, [vp, vp, sz, C.POINTER(sz)]),
         "cz_synchronize": (C.c_int, [vp]),
         "cz_debug_set": (C.c_int, [vp, C.c_char_p, C.c_long]),
@@ -281,6 +285,42 @@ def read_header(buf: bytes):
     h, off, used = Header(), C.c_size_t(), C.c_size_t()
     _check(lib().cz_read_header_v2(_p(a), len(buf), C.byref(h), C.byref(off), C.byref(used)))
     return h, bytes(buf[off.value:off.value + h.model_file_repr_len]), used.value
+
+
+class BpeTokenizer:
+    """HF byte-level BPE tokenizer.json, in-process (the `tokenizers` crate calls of src/main.rs:1812, 1852, 2654)"""
+
+    def __init__(self, tokenizer_json_path):
+        h = C.c_void_p()
+        _check(lib().cz_bpe_tokenizer_open(os.fsencode(tokenizer_json_path), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cz_bpe_tokenizer_close(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def vocab_size(self):
+        return int(lib().cz_bpe_vocab_size(self.h))
+
+    def encode(self, data: bytes):
+        """ids of String::from_utf8_lossy(data), no special tokens added (tok.encode(text, false))"""
+        a = np.frombuffer(data, np.uint8) if len(data) else np.zeros(1, np.uint8)
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(lib().cz_bpe_encode(self.h, a.ctypes.data, len(data), C.byref(out), C.byref(n)))
+        ids = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint32)), (max(n.value, 1),))[: n.value].copy()
+        lib().cz_free(out)
+        return ids
+
+    def decode(self, ids, skip_special_tokens=True) -> bytes:
+        a = np.ascontiguousarray(ids, np.uint32)
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(lib().cz_bpe_decode(self.h, a.ctypes.data if a.size else None, a.size, 1 if skip_special_tokens else 0, C.byref(out), C.byref(n)))
+        data = C.string_at(out, n.value) if n.value else b""
+        lib().cz_free(out)
+        return data
 
 
 def blake3_16(data: bytes) -> bytes:

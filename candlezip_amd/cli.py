@@ -7,9 +7,9 @@ Same flag names and defaults; agent / scan flags are accepted and rejected ("not
 being silently ignored.  `--cpu` is rejected: this build has no CPU path.  Extras for machines without checkpoints
 (none exist offline): `--synthetic SEED` (seeded weights) and `--token-ids FILE` (u32 ids instead of a tokenizer).
 
-The heavy lifting (session, token loops, coder, container, hashes) is libcandlezip_hip.so through the C ABI; SmolLM2
-tokenisation uses the HF `tokenizers` library (the same library the reference links as a crate, src/main.rs:1812, 1852,
-2654); the RWKV World tokenizer is the library's own (cz_rwkv_*).
+The heavy lifting (session, token loops, coder, container, hashes) is libcandlezip_hip.so through the C ABI; both
+tokenizers are the library's own: SmolLM2's HF byte-level BPE tokenizer.json (cz_bpe_*, replacing the `tokenizers` crate calls at
+src/main.rs:1812, 1852, 2654) and the RWKV World tokenizer (cz_rwkv_*).
 """
 import argparse
 import ctypes as C
@@ -84,6 +84,22 @@ def _hash_file(path):
     return out.tobytes()
 
 
+class _HfTokenizer:
+    """the HF library behind the interface of cz.BpeTokenizer (only for tokenizer.json layouts the in-process tokenizer refuses)"""
+
+    def __init__(self, tok):
+        self.tok = tok
+
+    def vocab_size(self):
+        return self.tok.get_vocab_size(True)
+
+    def encode(self, data: bytes):
+        return np.array(self.tok.encode(data.decode("utf-8", "replace"), add_special_tokens=False).ids, np.uint32)
+
+    def decode(self, ids, skip_special_tokens=True) -> bytes:
+        return self.tok.decode([int(i) for i in ids], skip_special_tokens=skip_special_tokens).encode("utf-8")
+
+
 class _Model:
     """weights + tokenizer + hashes for one backend (what encode_file / decode_file set up at src/main.rs:1799-1829, 2444-2466)"""
 
@@ -109,12 +125,18 @@ class _Model:
                 self.model_hash = _hash_files(paths)                                   # blake3_files_bin16 (:1810)
                 self.repr = os.path.basename(paths[0]).encode() if len(paths) == 1 else b"model.safetensors.index.json"
             if args.tokenizer:
-                from tokenizers import Tokenizer
-                self.tok = Tokenizer.from_file(args.tokenizer)
+                try:
+                    self.tok = cz.BpeTokenizer(args.tokenizer)                         # in-process byte-level BPE (csrc/cz_bpe.cpp), :1812
+                except cz.CandlezipError as e:
+                    if "CZ_ERR_UNSUPPORTED" not in str(e):
+                        raise
+                    from tokenizers import Tokenizer                                   # a layout the in-process tokenizer refuses: the HF library itself
+                    print(f"note: {e}; using the HF tokenizers library", file=sys.stderr)
+                    self.tok = _HfTokenizer(Tokenizer.from_file(args.tokenizer))
                 self.tok_hash = _hash_file(args.tokenizer)                             # :1811
             else:
                 self.tok_hash = bytes(16)
-            self.vocab = self.sess.vocab_size() if self.tok is None else self.tok.get_vocab_size(True)   # :1814
+            self.vocab = self.sess.vocab_size() if self.tok is None else self.tok.vocab_size()   # get_vocab_size(true), :1814
         else:
             if args.synthetic is not None:
                 self.sess = cz.Session("rwkv7", cz.rwkv7_0b1_config(), seed=args.synthetic, device=args.device, max_streams=1)
@@ -140,10 +162,9 @@ class _Model:
         if self.backend == "smollm":
             if self.tok is None:
                 sys.exit("error: --tokenizer tokenizer.json (or --token-ids) is required for --backend smollm")
-            text = data.decode("utf-8", "replace")                                     # String::from_utf8_lossy (:1852)
-            if text.encode("utf-8") != data:
+            if data.decode("utf-8", "replace").encode("utf-8") != data:               # String::from_utf8_lossy (:1852)
                 print("warning: input is not valid UTF-8; like the reference, the round trip will be lossy", file=sys.stderr)
-            return np.array(self.tok.encode(text, add_special_tokens=False).ids, np.uint32)
+            return np.asarray(self.tok.encode(data), np.uint32)
         if self.rwkv_tok is None:                                                      # complete fallback: literals (:863-868)
             return (np.frombuffer(data, np.uint8).astype(np.uint32) + self.vocab)
         L = cz.lib()
@@ -157,7 +178,7 @@ class _Model:
         if self.backend == "smollm":
             if self.tok is None:
                 sys.exit("error: --tokenizer is required to turn ids back into text (or decode with --token-ids to get ids)")
-            return self.tok.decode([int(i) for i in ids], skip_special_tokens=True).encode("utf-8")   # :2654
+            return self.tok.decode(ids, True)                                          # decode(ids, skip_special_tokens = true), :2654
         if self.rwkv_tok is None:
             return bytes(int(i) - self.vocab for i in ids if int(i) >= self.vocab)
         L = cz.lib()

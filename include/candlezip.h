@@ -126,6 +126,18 @@ cz_status cz_rwkv_plan_symbols(const cz_rwkv_tokenizer* t, const uint8_t* bytes,
 /* rwkv_detok_with_literals: *out malloc'd (cz_free) */
 cz_status cz_rwkv_detok(const cz_rwkv_tokenizer* t, const uint32_t* ids, size_t n, uint32_t vocab, uint8_t** out, size_t* out_len);
 
+/* SmolLM2 tokenizer: HF `tokenizers` byte-level BPE read from tokenizer.json (src/main.rs:1812 Tokenizer::from_file).
+ * Supported layout: BPE model, no normalizer, ByteLevel (optionally after Digits) pre-tokenizer, ByteLevel decoder; anything
+ * else is refused with CZ_ERR_UNSUPPORTED.  Outputs are malloc'd (cz_free). */
+typedef struct cz_bpe_tokenizer cz_bpe_tokenizer;
+cz_status cz_bpe_tokenizer_open(const char* tokenizer_json_path, cz_bpe_tokenizer** out);
+void cz_bpe_tokenizer_close(cz_bpe_tokenizer* t);
+size_t cz_bpe_vocab_size(const cz_bpe_tokenizer* t);                                     /* get_vocab_size(true) */
+/* tok.encode(String::from_utf8_lossy(data), false)  (src/main.rs:1852): ids without BOS */
+cz_status cz_bpe_encode(const cz_bpe_tokenizer* t, const uint8_t* utf8, size_t n, uint32_t** ids_out, size_t* n_ids);
+/* tokenizer.decode(ids, skip_special_tokens)  (src/main.rs:2654) */
+cz_status cz_bpe_decode(const cz_bpe_tokenizer* t, const uint32_t* ids, size_t n, int skip_special, uint8_t** out, size_t* out_len);
+
 /* anyhow::Error text of the last failing call on this thread */
 const char* cz_last_error(void);
 

@@ -53,3 +53,14 @@ def test_self_test_roundtrip_rwkv7_literals_and_smollm_ids(tmp_path):
     # a different model must be refused unless --force-mismatch (src/main.rs:2450-2459)
     r = _run("--synthetic", "2", "--token-ids", str(idf), "decompress", str(out), str(back))
     assert r.returncode != 0 and "model hash mismatch" in r.stderr
+
+
+@pytest.mark.gpu
+def test_self_test_text_roundtrip_with_in_process_bpe(tmp_path):
+    """the whole drop-in path on text: tokenizer.json (in-process byte-level BPE) -> ids -> GPU encode -> .canz -> GPU decode -> text"""
+    golden = os.path.join(ROOT, "tests", "golden")
+    src = tmp_path / "excerpt.txt"
+    src.write_bytes(open(os.path.join(golden, "inputs", "alice29.txt"), "rb").read()[2000:5000] + "\n caf\u00e9 1234 \u4e2d\u6587\n".encode())
+    r = _run("--synthetic", "3", "--tokenizer", os.path.join(golden, "bpe_test_tokenizer.json"), "self-test", str(src))
+    assert r.returncode == 0 and "Roundtrip OK" in r.stdout, r.stderr + r.stdout
+    assert (tmp_path / "excerpt.canz").read_bytes()[:4] == b"GTPZ" and (tmp_path / "excerpt.roundtrip.txt").read_bytes() == src.read_bytes()
