@@ -73,7 +73,7 @@ EXPORTS = [  # every symbol include/candlezip.h declares
     "cz_ac_encode_pairs", "cz_free", "cz_write_header_v2", "cz_read_header_v2", "cz_flags_pack", "cz_skip_gate_section",
     "cz_blake3_bytes_bin16", "cz_blake3_file_bin16", "cz_blake3_files_bin16", "cz_rwkv_tokenizer_open",
     "cz_rwkv_tokenizer_close", "cz_rwkv_plan_symbols", "cz_rwkv_detok", "cz_bpe_tokenizer_open", "cz_bpe_tokenizer_close",
-    "cz_bpe_vocab_size", "cz_bpe_encode", "cz_bpe_decode", "cz_last_error", "cz_profile_enable",
+    "cz_bpe_vocab_size", "cz_bpe_encode", "cz_bpe_decode", "cz_xe_bits_over_span", "cz_xe_bits_batch", "cz_last_error", "cz_profile_enable",
     "cz_profile_read", "cz_synchronize",
 ]
 
@@ -107,6 +107,8 @@ def lib():
         "cz_blake3_bytes_bin16": (None, [vp, sz, vp]), "cz_blake3_file_bin16": (C.c_int, [C.c_char_p, vp]),
         "cz_blake3_files_bin16": (C.c_int, [C.POINTER(C.c_char_p), sz, vp]),
         "cz_last_error": (C.c_char_p, []),
+        "cz_xe_bits_over_span": (C.c_int, [vp, vp, sz, vp, sz, vp, sz, C.POINTER(C.c_double)]),
+        "cz_xe_bits_batch": (C.c_int, [vp, sz, vp, vp, vp, vp, vp, vp, vp]),
         "cz_bpe_tokenizer_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]), "cz_bpe_tokenizer_close": (None, [vp]), "cz_bpe_vocab_size": (sz, [vp]),
         "cz_bpe_encode": (C.c_int, [vp, vp, sz, C.POINTER(vp), C.POINTER(sz)]),
         "cz_bpe_decode": (C.c_int, [vp, vp, sz, C.c_int, C.POINTER(vp), C.POINTER(sz)]),
@@ -224,6 +226,23 @@ class Session:
 
     def decode_tokens(self, payload, token_count, context_window=512, reprime_interval=512, bos=0):
         return self.decode_tokens_batch([payload], [token_count], context_window, reprime_interval, bos)[0]
+
+    # ---- cross_entropy_bits_over_span (src/main.rs:1725-1751)
+    def xe_bits_over_span(self, history, targets, hint=()):
+        return float(self.xe_bits_batch([history], [targets], [hint])[0])
+
+    def xe_bits_batch(self, histories, targets, hints=None):
+        n = len(targets)
+        hints = hints if hints is not None else [()] * n
+        hs = [np.ascontiguousarray(h, np.uint32) for h in histories]; gs = [np.ascontiguousarray(g, np.uint32) for g in hints]
+        ts = [np.ascontiguousarray(t, np.uint32) for t in targets]
+        pad = lambda arrs: [a if a.size else np.zeros(1, np.uint32) for a in arrs]
+        out = np.zeros(max(n, 1), np.float64)
+        lens = lambda arrs: np.array([a.size for a in arrs] or [0], np.uint64)
+        hp, gp, tp = pad(hs), pad(gs), pad(ts)
+        hl, gl, tl = lens(hs), lens(gs), lens(ts)                  # (kept alive across the call)
+        _check(lib().cz_xe_bits_batch(self.h, n, _ptr_array(hp), _p(hl), _ptr_array(gp), _p(gl), _ptr_array(tp), _p(tl), _p(out)))
+        return out[:n]
 
     # ---- measurement
     KINDS = ["gemm_bf16w_f32_mfma", "gemm_skinny_f32_mfma", "attention_f32_mfma", "rmsnorm", "rope", "swiglu", "embed", "cdf_pairs",

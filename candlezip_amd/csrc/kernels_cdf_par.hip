@@ -443,6 +443,80 @@ extern "C" void cz_debug_cdf_phases(unsigned long long* out16, int reset) {
 }
 #endif
 
+// f4 — the probability the floor-softmax (softmax_pdf_floor, src/main.rs:758-766) gives sym[row]: p = max(e_s / S, floor) / norm with
+// S = sum of exps and norm = sum of floored probabilities, both sequential f64 chains evaluated exactly in parallel as above.
+// Consumer: cross_entropy_bits_over_span (src/main.rs:1725-1751); -log2 and the running sum stay on the host (libm).
+template <int LMAX>
+__global__ __launch_bounds__(T_PAR) void xe_prob_kernel(const float* __restrict__ logits, int ld, int rows, int V, const uint32_t* __restrict__ sym,
+                                                        double* __restrict__ p_out, double* __restrict__ scratch_all, unsigned* __restrict__ fallback_count) {
+    __shared__ par_smem_t<LMAX> sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* scratch = scratch_all + (size_t)blockIdx.x * V;
+    int L = (V + T_PAR - 1) / T_PAR;
+    if (L >= 8) L = (L + 3) & ~3;
+    const int first = tid * L;
+    const int cnt = first >= V ? 0 : (V - first < L ? V - first : L);
+    unsigned long long ph_t = 0;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* l = logits + (size_t)row * ld;
+        if (tid == 0) { sm.flag = 0; sm.L = L; sm.n = V; }
+        float ef[LMAX];
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < LMAX; ++k) if (k < cnt) { ef[k] = l[first + k]; if (ef[k] > m) m = ef[k]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { float y = __shfl_xor(m, o); m = y > m ? y : m; }
+        if (lane == 0) sm.redf[wave] = m;
+        __syncthreads();
+        m = sm.redf[0];
+#pragma unroll
+        for (int w = 1; w < NWAVE; ++w) m = sm.redf[w] > m ? sm.redf[w] : m;
+        __syncthreads();
+        double csum_e = 0.0;
+#pragma unroll
+        for (int k = 0; k < LMAX; ++k) if (k < cnt) { ef[k] = cz_expf(ef[k] - m); csum_e += (double)ef[k]; }
+        const double sum = exact_seq_sum<LMAX>([&](int k) { return (double)ef[k]; }, csum_e, cnt, first, sm, scratch, false, nullptr, ph_t);
+        bool fallback = sm.flag != 0 || !(sum > 0.0);
+        auto fl = [&](int k) { const double p = (double)ef[k] / sum; return p > P_MIN ? p : P_MIN; };
+        double norm = 1.0;
+        if (!fallback) {
+            const double inv_sum = 1.0 / sum;
+            double cs = 0.0;
+#pragma unroll
+            for (int k = 0; k < LMAX; ++k) if (k < cnt) { const double p = (double)ef[k] * inv_sum; cs += p > P_MIN ? p : P_MIN; }
+            norm = exact_seq_sum<LMAX>(fl, cs, cnt, first, sm, scratch, false, nullptr, ph_t);
+            fallback = sm.flag != 0 || !(norm > 0.0);
+        }
+        const uint32_t s = sym[row];
+        if (fallback) {
+            if (tid == 0) {
+                if (fallback_count) atomicAdd(fallback_count, 1u);
+                pdf_ctx c;
+                pdf_prepare(c, l, V, 1);
+                p_out[row] = s < (uint32_t)V ? pdf_floor_at(c, (int)s) / c.norm : P_MIN;
+            }
+        } else {
+            if (s >= (uint32_t)V) { if (tid == 0) p_out[row] = P_MIN; }                 // pdf.get(sym).unwrap_or(ac_p_min())
+            else if (s >= (uint32_t)first && s < (uint32_t)(first + cnt)) {
+                double p = 0.0;
+#pragma unroll
+                for (int k = 0; k < LMAX; ++k) if (first + k == (int)s) p = fl(k) / norm;
+                p_out[row] = p;
+            }
+        }
+        __syncthreads();
+    }
+}
+hipError_t cz_launch_xe_probs(hipStream_t st, const float* logits, int ld, const uint32_t* sym, double* p_out, int rows, int vocab, unsigned* fallback_count,
+                              double* scratch) {
+    if (rows <= 0) return hipSuccess;
+    if (!scratch || vocab > T_PAR * LMAX_RWKV) return hipErrorInvalidValue;
+    const int grid = rows < CZ_CDF_PAR_MAX_GRID ? rows : CZ_CDF_PAR_MAX_GRID;
+    if (vocab <= T_PAR * LMAX_SMOLLM) hipLaunchKernelGGL((xe_prob_kernel<LMAX_SMOLLM>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, p_out, scratch, fallback_count);
+    else hipLaunchKernelGGL((xe_prob_kernel<LMAX_RWKV>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, p_out, scratch, fallback_count);
+    return hipGetLastError();
+}
+
 bool cz_cdf_par_supported(int vocab, int mode) { return mode == 0 ? vocab <= T_PAR * LMAX_SMOLLM : vocab + 256 <= T_PAR * LMAX_RWKV; }
 
 hipError_t cz_launch_cdf_pairs(hipStream_t st, const float* logits, int ld, const uint32_t* sym, uint32_t* c_lo, uint32_t* c_hi,

@@ -534,6 +534,87 @@ static cz_status encode_llama(cz_session* s, size_t n_streams, const uint32_t* c
     return CZ_OK;
 }
 
+// ------------------------------------------------------------------ f4: cross-entropy of target spans (src/main.rs:1725-1751)
+// Teacher-forced: every span is ONE causal forward over prime ++ targets[..n-1]; the logits rows that predict the targets go through
+// the floor-softmax kernel; -log2 and the running sum are host libm, in the reference's order.  All spans share the GEMMs.
+static cz_status xe_llama(cz_session* s, size_t n_spans, const uint32_t* const* hist, const size_t* n_hist, const uint32_t* const* hint, const size_t* n_hint,
+                          const uint32_t* const* tgt, const size_t* n_tgt, double* bits_out) {
+    const cz_llama_config& c = s->llama.cfg;
+    const size_t max_ctx = 512 - 1;                                  // max_context_length().saturating_sub(1)
+    struct Span { std::vector<uint32_t> toks; size_t np, nt; };
+    std::vector<Span> sp(n_spans);
+    for (size_t i = 0; i < n_spans; ++i) {
+        bits_out[i] = 0.0;
+        const size_t nt = n_tgt[i], nh = n_hist ? n_hist[i] : 0, ng = n_hint ? n_hint[i] : 0;
+        sp[i].nt = nt; sp[i].np = 0;
+        if (nt == 0) continue;                                        // :1726
+        const size_t hb = std::min(ng, max_ctx), ht = std::min(max_ctx - hb, nh);
+        if (ht + hb == 0) { cz_set_error("reprime called with empty history"); return CZ_ERR_ARG; }
+        auto& v = sp[i].toks;
+        v.insert(v.end(), hist[i] + (nh - ht), hist[i] + nh);
+        if (hb) v.insert(v.end(), hint[i], hint[i] + hb);
+        sp[i].np = v.size();
+        v.insert(v.end(), tgt[i], tgt[i] + nt - 1);                   // the last target is scored, never fed
+        for (uint32_t t : v) if (t >= (uint32_t)c.vocab) { cz_set_error("token id %u >= vocab %d", t, c.vocab); return CZ_ERR_ARG; }
+        if (v.size() > (size_t)CZ_MAX_CTX || v.size() > (size_t)c.max_pos) { cz_set_error("span of %zu positions exceeds the supported context (%d)", v.size(), CZ_MAX_CTX); return CZ_ERR_STATE; }
+    }
+    const int d = c.d_model, kvd = c.n_kv_heads * 64, nq = d + 2 * kvd;
+    size_t si = 0;
+    while (si < n_spans) {
+        size_t M = 0, sj = si; int max_rows = 0;
+        while (sj < n_spans) {
+            const size_t T = sp[sj].toks.size();
+            if (M && M + T > s->max_batch_rows) break;
+            M += T; max_rows = std::max(max_rows, (int)T); ++sj;
+        }
+        if (M == 0) { si = sj; continue; }
+        std::vector<uint32_t> tok(M), sym; std::vector<int> rowidx; std::vector<cz_seq_desc> sd; std::vector<cz_rope_desc> rd;
+        CZCHK(s->qkv.ensure(M * (size_t)nq * 4));
+        float* qkv = (float*)s->qkv.p;
+        size_t row = 0;
+        for (size_t q = si; q < sj; ++q) {
+            const size_t T = sp[q].toks.size();
+            if (!T) continue;
+            memcpy(tok.data() + row, sp[q].toks.data(), T * 4);
+            float* kb = qkv + row * nq + d;
+            sd.push_back({(int)row, (int)T, 0, nq, kb, kb + kvd, 0, 0});
+            rd.push_back({(int)row, (int)T, 0, nq, kb, kb + kvd, 0, 0});
+            for (size_t i = 0; i < sp[q].nt; ++i) { rowidx.push_back((int)(row + sp[q].np - 1 + i)); sym.push_back(tgt[q][i]); }
+            row += T;
+        }
+        const int nseq = (int)sd.size(); const size_t Lr = rowidx.size();
+        CZCHK(s->tok.ensure(M * 4)); CZCHK(s->seqd.ensure(nseq * sizeof(cz_seq_desc))); CZCHK(s->roped.ensure(nseq * sizeof(cz_rope_desc)));
+        CZCHK(s->rowidx.ensure(Lr * 4)); CZCHK(s->sym.ensure(Lr * 4)); CZCHK(s->clo.ensure(Lr * 8 + 16));     // clo holds the f64 probabilities here
+        HIPCHK(hipMemcpyAsync(s->tok.p, tok.data(), M * 4, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->seqd.p, sd.data(), nseq * sizeof(cz_seq_desc), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->roped.p, rd.data(), nseq * sizeof(cz_rope_desc), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->rowidx.p, rowidx.data(), Lr * 4, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->sym.p, sym.data(), Lr * 4, hipMemcpyHostToDevice, s->stream));
+        CZCHK(llama_body(s, (int)M, (const cz_seq_desc*)s->seqd.p, (const cz_rope_desc*)s->roped.p, nseq, max_rows, max_rows, 0, nullptr));
+        const size_t LB = s->logit_batch_rows;
+        CZCHK(s->logits.ensure(std::min(LB, Lr) * (size_t)c.vocab * 4));
+        for (size_t r0 = 0; r0 < Lr; r0 += LB) {
+            const int nr = (int)std::min(LB, Lr - r0);
+            CZCHK(llama_head(s, (const int*)s->rowidx.p + r0, nr, (float*)s->logits.p));
+            s->prof_begin(PK_CDF);
+            HIPCHK(cz_launch_xe_probs(s->stream, (const float*)s->logits.p, c.vocab, (const uint32_t*)s->sym.p + r0, (double*)s->clo.p + r0, nr, c.vocab, s->fallback_dev,
+                                      s->cdf_scratch));
+            s->prof_end(0, (double)nr * c.vocab * 4);
+        }
+        std::vector<double> p(Lr);
+        HIPCHK(hipMemcpyAsync(p.data(), s->clo.p, Lr * 8, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        size_t k = 0;
+        for (size_t q = si; q < sj; ++q) {
+            double bits = 0.0;
+            for (size_t i = 0; i < sp[q].nt; ++i) { double pi = p[k++]; if (!(pi > 1e-300)) pi = 1e-300; bits += -log2(pi); }   // bits += -p.max(1e-300).log2()
+            bits_out[q] = bits;
+        }
+        si = sj;
+    }
+    return CZ_OK;
+}
+
 // ------------------------------------------------------------------ decode (lock-step)
 static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs,
                                     uint32_t context_window, uint32_t R, uint32_t bos, uint32_t* const* out_ids) {
@@ -789,6 +870,18 @@ extern "C" cz_status cz_decode_tokens_batch(cz_session* s, size_t n_streams, con
 extern "C" cz_status cz_decode_tokens(cz_session* s, const uint8_t* payload, size_t len, size_t token_count, uint32_t context_window,
                                       uint32_t reprime_interval, uint32_t bos, uint32_t* out_ids) {
     return cz_decode_tokens_batch(s, 1, &payload, &len, &token_count, context_window, reprime_interval, bos, &out_ids);
+}
+
+extern "C" cz_status cz_xe_bits_batch(cz_session* s, size_t n_spans, const uint32_t* const* history, const size_t* n_history, const uint32_t* const* hint,
+                                      const size_t* n_hint, const uint32_t* const* targets, const size_t* n_targets, double* bits_out) {
+    if (!s || !targets || !n_targets || !bits_out || (n_history && !history) || (n_hint && !hint)) { cz_set_error("cz_xe_bits_batch: null argument"); return CZ_ERR_ARG; }
+    if (s->backend != CZ_BACKEND_SMOLLM) { cz_set_error("cz_xe_bits: only the smollm backend is supported (cross_entropy_bits_over_span_rwkv is not built)"); return CZ_ERR_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(s->device));
+    return xe_llama(s, n_spans, history, n_history, hint, n_hint, targets, n_targets, bits_out);
+}
+extern "C" cz_status cz_xe_bits_over_span(cz_session* s, const uint32_t* history, size_t n_history, const uint32_t* hint, size_t n_hint,
+                                          const uint32_t* targets, size_t n_targets, double* bits_out) {
+    return cz_xe_bits_batch(s, 1, &history, &n_history, &hint, &n_hint, &targets, &n_targets, bits_out);
 }
 
 extern "C" cz_status cz_profile_enable(cz_session* s, int on) {

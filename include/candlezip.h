@@ -91,6 +91,17 @@ cz_status cz_decode_tokens_batch(cz_session* s, size_t n_streams, const uint8_t*
                                  const size_t* token_counts, uint32_t context_window, uint32_t reprime_interval,
                                  uint32_t bos, uint32_t* const* out_ids);
 
+/* cross_entropy_bits_over_span (src/main.rs:1725-1751, floor-softmax :758-766), the scorer next to the coder on the same forward:
+ * prime = last min(511 - min(n_hint, 511), n_history) ids of history ++ first min(n_hint, 511) ids of hint; bits = sum over the targets of
+ * -log2(max(p(target | prime, earlier targets), 1e-300)).  Teacher-forced and batched on the GPU (one causal forward per span, all spans
+ * of a batch share the GEMMs); the session's single-stream state is left untouched.  Errors like the reference: empty prime ->
+ * CZ_ERR_ARG ("reprime called with empty history"); n_targets == 0 -> 0.0.  smollm backend only. */
+cz_status cz_xe_bits_over_span(cz_session* s, const uint32_t* history, size_t n_history, const uint32_t* hint, size_t n_hint,
+                               const uint32_t* targets, size_t n_targets, double* bits_out);
+cz_status cz_xe_bits_batch(cz_session* s, size_t n_spans, const uint32_t* const* history, const size_t* n_history,
+                           const uint32_t* const* hint, const size_t* n_hint, const uint32_t* const* targets, const size_t* n_targets,
+                           double* bits_out /* [n_spans] */);
+
 /* ArithmeticEncoder over precomputed intervals (src/main.rs:261-318, 353-399: new + encode_counts* + finish).
  * *payload is malloc'd by the library; release with cz_free.  *zero_width (optional) counts c_lo == c_hi events,
  * i.e. tokens the reference would encode undecodably. */

@@ -780,6 +780,40 @@ int czo_smollm_reprime_logits(czo_smollm* s, const uint32_t* hist, size_t n, flo
     if (rc == 0) s->index_pos += n;
     return rc;
 }
+
+/* f4 — cross_entropy_bits_over_span (src/main.rs:1725-1751): prime = tail of history (as much as fits beside the hint in
+ * max_context_length() - 1 = 511 positions) ++ hint; re-prime; then for every target: floor-softmax (src/main.rs:758-766), bits +=
+ * -log2(max(p, 1e-300)), step(target).  Returns 0, or the session error (-3: empty prime).  If p_out != NULL it receives the n_t
+ * probabilities (what a device implementation has to reproduce bit for bit; the log2 and the running sum are host libm work). */
+int czo_smollm_xe_bits_over_span(czo_smollm* s, const uint32_t* history, size_t n_hist, const uint32_t* hint, size_t n_hint,
+                                 const uint32_t* targets, size_t n_t, double* bits_out, double* p_out) {
+    *bits_out = 0.0;
+    if (n_t == 0) return 0;                                              /* :1726 */
+    const size_t max_ctx = 512 - 1;                                      /* max_context_length().saturating_sub(1), src/models.rs:91 */
+    const size_t hint_budget = n_hint < max_ctx ? n_hint : max_ctx;
+    const size_t remaining = max_ctx - hint_budget;
+    const size_t hist_take = remaining < n_hist ? remaining : n_hist;
+    uint32_t* prime = (uint32_t*)malloc(sizeof(uint32_t) * (hist_take + hint_budget + 1));
+    size_t np = 0;
+    for (size_t i = 0; i < hist_take; ++i) prime[np++] = history[n_hist - hist_take + i];
+    for (size_t i = 0; i < hint_budget; ++i) prime[np++] = hint[i];
+    const size_t V = czo_smollm_vocab(s);
+    float* logits = (float*)malloc(sizeof(float) * V);
+    double* pdf = (double*)malloc(sizeof(double) * V);
+    int rc = czo_smollm_reprime_logits(s, prime, np, logits);
+    double bits = 0.0;
+    for (size_t i = 0; i < n_t && rc == 0; ++i) {
+        czo_softmax_pdf_floor(logits, V, czo_ac_p_min(), pdf);
+        double p = targets[i] < V ? pdf[targets[i]] : czo_ac_p_min();    /* pdf.get(sym).unwrap_or(ac_p_min()) */
+        if (p_out) p_out[i] = p;
+        if (!(p > 1e-300)) p = 1e-300;                                   /* p.max(1e-300) */
+        bits += -log2(p);
+        rc = czo_smollm_step_logits(s, targets[i], logits);
+    }
+    free(prime); free(logits); free(pdf);
+    *bits_out = bits;
+    return rc;
+}
 int czo_smollm_forward_rows(czo_smollm* s, const uint32_t* toks, size_t n, size_t first_row, float* logits) {
     s->index_pos = 0;
     int rc = llama_forward(s, toks, n, 0, first_row, logits);

@@ -110,6 +110,9 @@ int czo_smollm_step_logits(czo_smollm* s, uint32_t token, float* logits);
 /* src/models.rs:104-119 */
 int czo_smollm_reprime_logits(czo_smollm* s, const uint32_t* hist, size_t n, float* logits);
 /* raw bf16 weight access so the tests can hand the SAME tensors to the HIP library */
+/* cross_entropy_bits_over_span (src/main.rs:1725-1751) */
+int czo_smollm_xe_bits_over_span(czo_smollm* s, const uint32_t* history, size_t n_hist, const uint32_t* hint, size_t n_hint,
+                                 const uint32_t* targets, size_t n_t, double* bits_out, double* p_out);
 const uint16_t* czo_smollm_tensor_bf16(const czo_smollm* s, const char* name, size_t* numel);
 /* batched causal forward at positions 0..n-1, logits for rows [first_row, n) (n - first_row rows x vocab).
  * Used to check "step == batched" (the property segment-parallel encode relies on). */

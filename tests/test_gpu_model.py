@@ -95,7 +95,29 @@ def test_real_text_ids_canz_identical_to_oracle(cz, czo, golden):
     assert rep == b"synthetic:5" and hh.token_count == 1200
     out = g.decode_tokens(blobs[0][used:], 1200)
     assert np.array_equal(out, x)
+    # the span scorer on the same real ids at the full vocabulary width (f4)
+    assert g.xe_bits_over_span(x[:700], x[700:760], x[900:930]) == o.xe_bits_over_span(x[:700], x[700:760], x[900:930])[0]
     g.close(); o.close()
+
+
+def test_cross_entropy_bits_over_span_matches_oracle(cz, czo, tiny_pair):
+    """cross_entropy_bits_over_span (src/main.rs:1725-1751).  The probabilities are reproduced bit for bit (floor-softmax
+    chains evaluated exactly in parallel); -log2 and the sum are libm on both sides, so the bits are compared for equality too."""
+    g, o = tiny_pair
+    rng = np.random.default_rng(17)
+    hist = rng.integers(0, 512, 900).astype(np.uint32)
+    cases = [(hist, rng.integers(0, 512, 64), ()), (hist[:40], rng.integers(0, 512, 5), ()), (hist, rng.integers(0, 512, 128), rng.integers(0, 512, 48)),
+             ((), rng.integers(0, 512, 9), rng.integers(0, 512, 600)),                    # hint longer than the 511 budget: truncated, no history left
+             (hist, (), ()), (hist[:1], [7], ()), (hist, rng.integers(0, 512, 700), rng.integers(0, 512, 100))]
+    want = [o.xe_bits_over_span(h, t, hint)[0] for h, t, hint in cases]
+    got = g.xe_bits_batch([c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases])
+    assert got.tolist() == want
+    assert g.xe_bits_over_span(hist, cases[0][1]) == want[0] and want[4] == 0.0
+    with pytest.raises(cz.CandlezipError) as e:
+        g.xe_bits_over_span((), [1, 2, 3])
+    assert "empty history" in str(e.value)                                              # the reference's reprime error
+    # a target outside the vocabulary scores ac_p_min (pdf.get(sym).unwrap_or(p_min)) in the oracle; the device path refuses ids it cannot feed
+    assert g.debug_get("cdf_fallback_rows") == 0
 
 
 def test_context_1024_and_small_intervals(cz, czo, tiny_pair):
