@@ -92,6 +92,54 @@ def self_test_step(cz, sess, streams, context, reprime):
     return sum(s.size - 1 for s in streams), sum(len(p) for p in payloads), t1 - t0, t2 - t1
 
 
+def self_test_pipelined(cz, enc_sess, dec_sessions, streams, group, context, reprime):
+    """The same work as self_test_step, scheduled as a pipeline over groups of `group` streams: the compute-bound compress of group
+    k + 1 (big-M MFMA GEMMs) runs while the latency-bound lock-step decompress of groups <= k is in flight on the decode sessions
+    (one per lane: own HIP stream, KV cache and step graph).  Returns (tokens, payload_bytes, compress busy s, decompress busy s)."""
+    import threading
+    groups = [streams[i:i + group] for i in range(0, len(streams), group)]
+    L = len(dec_sessions)
+    lane_thread = [None] * L
+    err = []; stats = {"bytes": 0, "dec_busy": 0.0}
+    lock = threading.Lock()
+
+    def dec_worker(lane, grp, payloads):
+        try:
+            t = time.perf_counter()
+            outs = dec_sessions[lane].decode_tokens_batch(payloads, [s.size - 1 for s in grp], context, reprime, 0)
+            dt = time.perf_counter() - t
+            for s, o in zip(grp, outs):
+                if not np.array_equal(s, o):
+                    raise RuntimeError("self-test round trip mismatch")
+            with lock:
+                stats["dec_busy"] += dt
+        except Exception as e:      # noqa
+            err.append(e)
+
+    t0 = time.perf_counter(); enc_busy = 0.0
+    for g, grp in enumerate(groups):
+        t = time.perf_counter()
+        pairs = enc_sess.encode_tokens_batch(grp, context, reprime)
+        payloads = [cz.ac_encode_pairs(lo, hi)[0] for lo, hi in pairs]
+        enc_busy += time.perf_counter() - t
+        stats["bytes"] += sum(len(p) for p in payloads)
+        lane = g % L
+        if lane_thread[lane] is not None:
+            lane_thread[lane].join()
+        lane_thread[lane] = threading.Thread(target=dec_worker, args=(lane, grp, payloads))
+        lane_thread[lane].start()
+    for t in lane_thread:
+        if t is not None:
+            t.join()
+    if err:
+        raise err[0]
+    wall = time.perf_counter() - t0
+    n = sum(s.size - 1 for s in streams)
+    note(f"self-test pass (pipelined, {len(groups)} groups on {L} decode lanes): {n} tokens in {wall:.1f}s; compress busy {enc_busy:.1f}s, "
+         f"decompress busy {stats['dec_busy']:.1f}s (lane-seconds), round trip exact")
+    return n, stats["bytes"], enc_busy, stats["dec_busy"]
+
+
 def cpu_baseline(sample_tokens, context, reprime):
     """the oracle (CPU restatement of the reference path) in the REFERENCE's schedule: one M=1 forward per token, a
     511-token batched re-prime every `reprime` tokens, host softmax->CDF->coder per token.  Bounded sample."""
@@ -122,7 +170,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=384, help="streams (64 KiB chunks) per GPU, decoded in lock-step")
     ap.add_argument("--lanes", type=int, default=3, help="concurrent lock-step decode groups per GPU (library decode lanes)")
+    ap.add_argument("--pipeline", type=int, default=0, help="1: compress group k+1 while groups <= k decompress (one decode session per lane)")
     ap.add_argument("--no-graph", action="store_true", help="launch the decode step eagerly (needed under rocprofv3 --pmc)")
+    ap.add_argument("--dec-nw-cap", type=int, default=0, help="tuning: waves per decode GEMM block (0 = library default 12)")
     ap.add_argument("--dec-grid-target", type=int, default=0, help="tuning: blocks per decode GEMM launch (0 = library default)")
     ap.add_argument("--lane-streams", type=int, default=128, help="streams per lock-step group")
     ap.add_argument("--warmup-tokens", type=int, default=1100, help="tokens/stream of a warmup step")
@@ -154,8 +204,19 @@ def main():
     sess.debug_set("max_lanes", args.lanes)
     if args.no_graph:
         sess.debug_set("no_graph", 1)
+    if args.dec_nw_cap:
+        sess.debug_set("dec_nw_cap", args.dec_nw_cap)
     if args.dec_grid_target:
         sess.debug_set("dec_grid_target", args.dec_grid_target)
+    dec_sessions = []
+    if args.pipeline:
+        nl = min(args.lanes, -(-args.streams // min(256, args.streams, args.lane_streams)))
+        dec_sessions = [sess.fork() for _ in range(nl)]        # same device weights, own stream / KV cache / step graph
+
+    def run_self_test(strs):
+        if args.pipeline:
+            return self_test_pipelined(cz, sess, dec_sessions, strs, min(256, args.streams, args.lane_streams), args.context, args.reprime_interval)
+        return self_test_step(cz, sess, strs, args.context, args.reprime_interval)
     streams = make_streams(rank, args.streams, args.tokens, cfg.vocab)   # files shard across ranks: no data-path collective
     note(f"rank {rank}/{world}: session open, {args.streams} streams x {args.tokens} tokens")
 
@@ -170,7 +231,7 @@ def main():
     sess.profile_enable(False)
     warm = [s[: args.warmup_tokens + 1] for s in streams]
     for _ in range(args.warmup):
-        self_test_step(cz, sess, warm, args.context, args.reprime_interval)
+        run_self_test(warm)
 
     # timed region: exactly K steps.  The big-M MFMA GEMM family (launched eagerly) is HIP-event timed on the library's
     # stream inside this region; the decode-step kernels run inside hipGraphs and cannot be bracketed one by one.
@@ -179,7 +240,7 @@ def main():
     t0 = time.perf_counter()
     tok = byt = 0; te = td = 0.0
     for _ in range(args.steps):
-        n, b, e, d = self_test_step(cz, sess, streams, args.context, args.reprime_interval)
+        n, b, e, d = run_self_test(streams)
         tok += n; byt += b; te += e; td += d
     barrier()
     elapsed = time.perf_counter() - t0
@@ -248,6 +309,8 @@ def main():
         if world == 1 and args.cpu_sample > 0 and not args.tiny:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.context, args.reprime_interval)
         print(json.dumps(line), flush=True)
+    for d_ in dec_sessions:
+        d_.close()
     sess.close()
     if dist is not None:
         dist.barrier()

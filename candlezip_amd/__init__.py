@@ -68,7 +68,7 @@ def tiny_rwkv7_config(vocab=512, hidden=128, n_layers=2, d_ffn=512):
 
 
 EXPORTS = [  # every symbol include/candlezip.h declares
-    "cz_session_open", "cz_session_close", "cz_vocab_size", "cz_max_context_length", "cz_index_pos", "cz_step_logits",
+    "cz_session_open", "cz_session_close", "cz_session_fork", "cz_vocab_size", "cz_max_context_length", "cz_index_pos", "cz_step_logits",
     "cz_reprime_logits", "cz_encode_tokens", "cz_encode_tokens_batch", "cz_decode_tokens", "cz_decode_tokens_batch",
     "cz_ac_encode_pairs", "cz_free", "cz_write_header_v2", "cz_read_header_v2", "cz_flags_pack", "cz_skip_gate_section",
     "cz_blake3_bytes_bin16", "cz_blake3_file_bin16", "cz_blake3_files_bin16", "cz_rwkv_tokenizer_open",
@@ -92,7 +92,7 @@ def lib():
     vp, sz, u32, u64 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64
     sig = {
         "cz_session_open": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(vp)]),
-        "cz_session_close": (None, [vp]), "cz_vocab_size": (sz, [vp]), "cz_max_context_length": (sz, [vp]), "cz_index_pos": (sz, [vp]),
+        "cz_session_close": (None, [vp]), "cz_session_fork": (C.c_int, [vp, C.POINTER(vp)]), "cz_vocab_size": (sz, [vp]), "cz_max_context_length": (sz, [vp]), "cz_index_pos": (sz, [vp]),
         "cz_step_logits": (C.c_int, [vp, u32, vp]), "cz_reprime_logits": (C.c_int, [vp, vp, sz, vp]),
         "cz_encode_tokens": (C.c_int, [vp, vp, sz, u32, u32, vp, vp]),
         "cz_encode_tokens_batch": (C.c_int, [vp, sz, vp, vp, u32, u32, vp, vp]),
@@ -169,6 +169,15 @@ class Session:
         self.h = C.c_void_p()
         _check(L.cz_session_open(C.byref(d), device, C.byref(self.h)))
         self.V = int(L.cz_vocab_size(self.h))
+
+    def fork(self):
+        """a second, independent session on the same device weights (cz_session_fork); close it before this one"""
+        f = object.__new__(Session)
+        f.h = C.c_void_p()
+        _check(lib().cz_session_fork(self.h, C.byref(f.h)))
+        f.V = self.V
+        f._parent = self                                         # keeps the weights' owner alive
+        return f
 
     def close(self):
         if getattr(self, "h", None):

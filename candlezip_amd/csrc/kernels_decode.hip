@@ -262,7 +262,8 @@ __global__ __launch_bounds__(768) void dec_gemm_group_kernel(dec_gemm_group g) {
     dec_gemm_body<EPI_PLAIN, 0, MT>(g.a[z], blockIdx.x, blockIdx.y);
 }
 
-static int dec_nw(int K) { int nch = K / 64; nch = nch < 12 ? nch : 12; return nch < 4 ? 4 : nch; }   // >= 256 threads: one per element of a tile
+int g_dec_nw_cap = 12;           // tuning knob (cz_debug_set "dec_nw_cap"): waves per decode-GEMM block (each wave owns K chunks round-robin)
+static int dec_nw(int K) { int nch = K / 64; nch = nch < g_dec_nw_cap ? nch : g_dec_nw_cap; return nch < 4 ? 4 : nch; }   // >= 256 threads: one per element of a tile
 template <int EPI, int NORM, int MT>
 static hipError_t dec_gemm_launch_mt(hipStream_t st, const dec_gemm_args& a, int gx) {
     const int NW = dec_nw(a.K);

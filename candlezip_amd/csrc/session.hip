@@ -25,6 +25,7 @@
 
 extern int g_attn_v1;
 extern int g_dec_grid_target;
+extern int g_dec_nw_cap;
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t _e = (expr);                                                                        \
@@ -739,6 +740,8 @@ extern "C" cz_status cz_session_open(const cz_model_desc* desc, int device_ordin
 }
 extern "C" void cz_session_close(cz_session* s) {
     if (!s) return;
+    if (s->fork_of) { s->fork_of->n_forks -= 1; }
+    else if (s->n_forks > 0) fprintf(stderr, "candlezip: closing a session that still has %d fork(s): their weights are gone\n", s->n_forks);
     hipSetDevice(s->device);
     for (cz_session* l : s->lanes) cz_session_close(l);
     s->lanes.clear();
@@ -872,6 +875,19 @@ extern "C" cz_status cz_decode_tokens(cz_session* s, const uint8_t* payload, siz
     return cz_decode_tokens_batch(s, 1, &payload, &len, &token_count, context_window, reprime_interval, bos, &out_ids);
 }
 
+// a second, independent session on the SAME device tensors (the reference loads the model a second time for that, src/main.rs:1943-1956)
+extern "C" cz_status cz_session_fork(cz_session* parent, cz_session** out) {
+    if (!parent || !out) { cz_set_error("cz_session_fork: null argument"); return CZ_ERR_ARG; }
+    *out = nullptr;
+    if (parent->is_lane) { cz_set_error("cz_session_fork: fork the original session, not a fork"); return CZ_ERR_ARG; }
+    HIPCHK(hipSetDevice(parent->device));
+    cz_session* c = nullptr;
+    CZCHK(make_lane(parent, &c));
+    c->max_lanes = parent->max_lanes;                       // a fork may run its own lanes
+    c->fork_of = parent; parent->n_forks += 1;
+    *out = c;
+    return CZ_OK;
+}
 extern "C" cz_status cz_xe_bits_batch(cz_session* s, size_t n_spans, const uint32_t* const* history, const size_t* n_history, const uint32_t* const* hint,
                                       const size_t* n_hint, const uint32_t* const* targets, const size_t* n_targets, double* bits_out) {
     if (!s || !targets || !n_targets || !bits_out || (n_history && !history) || (n_hint && !hint)) { cz_set_error("cz_xe_bits_batch: null argument"); return CZ_ERR_ARG; }
@@ -926,6 +942,7 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "max_lanes")) s->max_lanes = (int)value;
     else if (!strcmp(key, "probe_launch")) s->probe_launch = (int)value;
     else if (!strcmp(key, "dec_grid_target")) g_dec_grid_target = (int)value;
+    else if (!strcmp(key, "dec_nw_cap")) g_dec_nw_cap = (int)value < 4 ? 4 : ((int)value > 12 ? 12 : (int)value);
     else { cz_set_error("unknown debug key %s", key); return CZ_ERR_ARG; }
     return CZ_OK;
 }

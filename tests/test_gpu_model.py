@@ -120,6 +120,33 @@ def test_cross_entropy_bits_over_span_matches_oracle(cz, czo, tiny_pair):
     assert g.debug_get("cdf_fallback_rows") == 0
 
 
+def test_session_fork_shares_weights(cz, czo, tiny_pair):
+    """cz_session_fork: a second independent session on the same device tensors — same bits, independent state, usable from another
+    host thread while the parent works (the reference loads the model twice for its second session, src/main.rs:1943-1956)"""
+    import threading
+    g, o = tiny_pair
+    rng = np.random.default_rng(23)
+    a = np.concatenate([[0], rng.integers(0, 512, 900)]).astype(np.uint32); b = np.concatenate([[0], rng.integers(0, 512, 700)]).astype(np.uint32)
+    f = g.fork()
+    assert f.vocab_size() == g.vocab_size()
+    ref_a = g.encode_tokens(a); pay_a = cz.ac_encode_pairs(*ref_a)[0]
+    out = {}
+    t = threading.Thread(target=lambda: out.setdefault("b", f.encode_tokens(b)))           # the fork compresses ...
+    t.start()
+    dec_a = g.decode_tokens(pay_a, a.size - 1)                                              # ... while the parent decompresses
+    t.join()
+    assert np.array_equal(dec_a, a)
+    ref_b = g.encode_tokens(b)
+    assert np.array_equal(out["b"][0], ref_b[0]) and np.array_equal(out["b"][1], ref_b[1])
+    _eq(f.reprime_with_history_and_get_last_logits_tensor(a[:50]), g.reprime_with_history_and_get_last_logits_tensor(a[:50]), "fork reprime")
+    assert f.index_pos() == 50
+    g.step_logits_tensor(5)
+    assert g.index_pos() == 51 and f.index_pos() == 50                                      # independent state
+    with pytest.raises(cz.CandlezipError):
+        f.fork()
+    f.close()
+
+
 def test_context_1024_and_small_intervals(cz, czo, tiny_pair):
     g, o = tiny_pair
     rng = np.random.default_rng(2)
