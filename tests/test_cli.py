@@ -64,3 +64,17 @@ def test_self_test_text_roundtrip_with_in_process_bpe(tmp_path):
     r = _run("--synthetic", "3", "--tokenizer", os.path.join(golden, "bpe_test_tokenizer.json"), "self-test", str(src))
     assert r.returncode == 0 and "Roundtrip OK" in r.stdout, r.stderr + r.stdout
     assert (tmp_path / "excerpt.canz").read_bytes()[:4] == b"GTPZ" and (tmp_path / "excerpt.roundtrip.txt").read_bytes() == src.read_bytes()
+
+
+@pytest.mark.gpu
+def test_corpus_self_test_on_reference_inputs():
+    """BASELINE config 3 on the committed reference inputs: 64 KiB chunks of alice29 / asyoulik / enwik8_128kb_0 / fields.c, tokenised
+    in-process, compressed and decompressed as one lock-step batch; every chunk must come back (up to the reference's own from_utf8_lossy)"""
+    import json
+    golden = os.path.join(ROOT, "tests", "golden")
+    files = [os.path.join(golden, "inputs", n) for n in ("alice29.txt", "asyoulik.txt", "enwik8_128kb_0", "fields.c")]
+    r = subprocess.run([sys.executable, "-m", "candlezip_amd.corpus", "--synthetic", "5", "--tokenizer", os.path.join(golden, "bpe_test_tokenizer.json"),
+                        "--chunk-bytes", "16384", "--max-streams", "32", *files], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["roundtrip_failures"] == [] and d["chunks"] == 10 + 8 + 8 + 1 and d["tokens"] > 100000 and d["self_test_tokens_per_s"] > 0
