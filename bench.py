@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=3, help="concurrent lock-step decode groups per GPU (library decode lanes)")
     ap.add_argument("--pipeline", type=int, default=0, help="1: compress group k+1 while groups <= k decompress (one decode session per lane)")
     ap.add_argument("--no-graph", action="store_true", help="launch the decode step eagerly (needed under rocprofv3 --pmc)")
+    ap.add_argument("--kv-ctx-cap", type=int, default=0, help="tuning: positions per stream in the KV cache (0 = library default 2048)")
     ap.add_argument("--dec-nw-cap", type=int, default=0, help="tuning: waves per decode GEMM block (0 = library default 12)")
     ap.add_argument("--dec-grid-target", type=int, default=0, help="tuning: blocks per decode GEMM launch (0 = library default)")
     ap.add_argument("--lane-streams", type=int, default=128, help="streams per lock-step group")
@@ -204,6 +205,8 @@ def main():
     sess.debug_set("max_lanes", args.lanes)
     if args.no_graph:
         sess.debug_set("no_graph", 1)
+    if args.kv_ctx_cap:
+        sess.debug_set("kv_ctx_cap", args.kv_ctx_cap)
     if args.dec_nw_cap:
         sess.debug_set("dec_nw_cap", args.dec_nw_cap)
     if args.dec_grid_target:

@@ -57,7 +57,7 @@ struct cz_session {
     }
     // lock-step streams
     int max_streams = 64;
-    size_t ctx_cap = 0, kv_layer_stride = 0, kv_stream_stride = 0;
+    size_t ctx_cap = 0, kv_layer_stride = 0, kv_stream_stride = 0; int kv_ctx_cap = 0;   // kv_ctx_cap: requested positions per stream (0 = CZ_MAX_CTX)
     float* kvcache = nullptr;          // [stream][layer][K|V][ctx_cap][n_kv*64]
     int* pos_dev = nullptr;
     cz_seq_desc* step_seqd = nullptr; cz_rope_desc* step_roped = nullptr; int* step_rows = nullptr;

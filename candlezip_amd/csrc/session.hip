@@ -304,7 +304,7 @@ static cz_status ensure_streams(cz_session* s, int B) {
     const size_t kvd = (size_t)c.n_kv_heads * 64;
     if (B > s->max_streams) { cz_set_error("%d streams exceed max_streams = %d", B, s->max_streams); return CZ_ERR_ARG; }
     if (!s->kvcache) {
-        s->ctx_cap = CZ_MAX_CTX;
+        s->ctx_cap = s->kv_ctx_cap ? (size_t)s->kv_ctx_cap : (size_t)CZ_MAX_CTX;
         s->kv_layer_stride = 2 * s->ctx_cap * kvd;
         s->kv_stream_stride = (size_t)c.n_layers * s->kv_layer_stride;
         HIPCHK(hipMalloc((void**)&s->kvcache, (size_t)s->max_streams * s->kv_stream_stride * 4));
@@ -365,7 +365,7 @@ static cz_status llama_step_fast(cz_session* s, int B, int pos, int max_nk) {
 }
 // one token per stream at position `pos` (tokens in s->tok[0..B)); logits -> s->step_logits [B][V]
 static cz_status llama_step(cz_session* s, int B, int pos) {
-    if (pos >= CZ_MAX_CTX || pos >= s->llama.cfg.max_pos) { cz_set_error("position %d exceeds the supported context (%d)", pos, CZ_MAX_CTX); return CZ_ERR_STATE; }
+    if (pos >= CZ_MAX_CTX || pos >= s->llama.cfg.max_pos || (s->ctx_cap && pos >= (int)s->ctx_cap)) { cz_set_error("position %d exceeds the supported context (%d)", pos, CZ_MAX_CTX); return CZ_ERR_STATE; }
     hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, pos);
     if (!s->decode_v1 && s->llama.cfg.n_heads / s->llama.cfg.n_kv_heads <= 4) return llama_step_fast(s, B, pos, pos + 1);
     if (B > 64) s->force_big_gemm = 1;                     // the general skinny kernel covers M <= 64 only
@@ -374,7 +374,7 @@ static cz_status llama_step(cz_session* s, int B, int pos) {
 }
 // re-prime: every stream forwards hl tokens (s->tok[b*hl + j]) at positions 0..hl-1 into its cache; logits of the last row
 static cz_status llama_reprime(cz_session* s, int B, int hl) {
-    if (hl <= 0 || hl > CZ_MAX_CTX) { cz_set_error("history length %d out of range", hl); return CZ_ERR_ARG; }
+    if (hl <= 0 || hl > CZ_MAX_CTX || (s->ctx_cap && hl > (int)s->ctx_cap)) { cz_set_error("history length %d out of range", hl); return CZ_ERR_ARG; }
     const size_t kvd = (size_t)s->llama.cfg.n_kv_heads * 64;
     std::vector<cz_seq_desc> sd(B); std::vector<cz_rope_desc> rd(B); std::vector<int> ri(B);
     for (int b = 0; b < B; ++b) {
@@ -674,7 +674,7 @@ static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* 
             index_pos = hl;
             hipLaunchKernelGGL(set_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, (int)index_pos, (unsigned long long)i);
         }
-        if (index_pos >= (size_t)CZ_MAX_CTX) { cz_set_error("position %zu exceeds the supported context (%d)", index_pos, CZ_MAX_CTX); return CZ_ERR_STATE; }
+        if (index_pos >= (size_t)CZ_MAX_CTX || index_pos >= s->ctx_cap) { cz_set_error("position %zu exceeds the supported context (%d)", index_pos, CZ_MAX_CTX); return CZ_ERR_STATE; }
         if (use_graph) {
             if (s->probe_launch && i < 64) HIPCHK(hipStreamSynchronize(s->stream));          // probe: cost of a launch into an empty queue
             timespec c0, c1; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c0);
@@ -827,7 +827,7 @@ static cz_status run_on_lanes(cz_session* s, size_t n_streams, GroupFn group) {
     auto run = [&](size_t l) {
         cz_session* ls = l == 0 ? s : s->lanes[l - 1];
         if (hipSetDevice(s->device) != hipSuccess) { rc[l] = CZ_ERR_HIP; msg[l] = "hipSetDevice failed"; return; }
-        if (l) { ls->serial_cdf = s->serial_cdf; ls->decode_v1 = s->decode_v1; ls->no_graph = s->no_graph; ls->force_big_gemm = s->force_big_gemm;
+        if (l) { ls->kv_ctx_cap = s->kv_ctx_cap; ls->serial_cdf = s->serial_cdf; ls->decode_v1 = s->decode_v1; ls->no_graph = s->no_graph; ls->force_big_gemm = s->force_big_gemm;
                  ls->max_batch_rows = s->max_batch_rows; ls->logit_batch_rows = s->logit_batch_rows; }
         for (size_t g = l; g < G && rc[l] == CZ_OK; g += L) {
             rc[l] = group(ls, off[g], off[g + 1] - off[g]);
@@ -940,6 +940,7 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "no_graph")) s->no_graph = (int)value;
     else if (!strcmp(key, "attn_v1")) g_attn_v1 = (int)value;
     else if (!strcmp(key, "max_lanes")) s->max_lanes = (int)value;
+    else if (!strcmp(key, "kv_ctx_cap")) { if (s->kvcache) { cz_set_error("kv_ctx_cap must be set before the first step / decode"); return CZ_ERR_STATE; } s->kv_ctx_cap = (int)value; }
     else if (!strcmp(key, "probe_launch")) s->probe_launch = (int)value;
     else if (!strcmp(key, "dec_grid_target")) g_dec_grid_target = (int)value;
     else if (!strcmp(key, "dec_nw_cap")) g_dec_nw_cap = (int)value < 4 ? 4 : ((int)value > 12 ? 12 : (int)value);
