@@ -178,12 +178,16 @@ def main():
     ap.add_argument("--lane-streams", type=int, default=128, help="streams per lock-step group")
     ap.add_argument("--warmup-tokens", type=int, default=1100, help="tokens/stream of a warmup step")
     ap.add_argument("--profile-tokens", type=int, default=600, help="tokens/stream of the untimed per-family profiling pass")
-    ap.add_argument("--tokens", type=int, default=17408, help="tokens per stream (~ one 64 KiB enwik8 sample)")
+    ap.add_argument("--tokens", type=int, default=0,
+                    help="tokens per stream and step; default: one 64 KiB enwik8 sample (17408 tokens) spread over the K steps, "
+                         "i.e. max(2048, 17408 / K rounded up to 512), so that the whole run stays within minutes for any K")
     ap.add_argument("--context", type=int, default=512)
     ap.add_argument("--reprime-interval", type=int, default=512)
     ap.add_argument("--cpu-sample", type=int, default=640, help="tokens of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check only)")
     args = ap.parse_args()
+    if args.tokens <= 0:
+        args.tokens = 17408 if args.steps <= 1 else max(2048, ((17408 + args.steps - 1) // args.steps + 511) // 512 * 512)
 
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -310,7 +314,8 @@ def main():
             "value": round(total_tok / elapsed, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"enwik8 64 KiB samples, chunk-sharded: {args.streams} streams x {args.tokens} tokens per GPU, "
+            "config": {"workload": f"enwik8 64 KiB samples, chunk-sharded: {args.streams} streams x {args.tokens} tokens per GPU and step"
+                                   f"{'' if args.tokens == 17408 else ' (a 17408-token sample spread over the steps)'}, "
                                    f"SmolLM2-135M shape ({'tiny test model' if args.tiny else 'd576 L30 9q/3kv ffn1536 V49152'}), "
                                    f"context {args.context}, reprime_interval {args.reprime_interval}, seeded synthetic weights",
                        "streams_per_gpu": args.streams, "decode_lanes": min(args.lanes, -(-args.streams // min(256, args.streams, args.lane_streams))),
