@@ -213,6 +213,32 @@ def test_smollm2_135m_shape_bitexact(cz, czo):
     g.close(); o.close()
 
 
+def test_other_llama_family_shape_bitexact(cz, czo):
+    """a second LLaMA-family shape through the same kernels (SmolLM2-360M's geometry: d 960, 15/5 heads, ffn 2560, rope 1e5; 6 of its 32
+    layers to keep the CPU oracle quick): different K-chunk counts (15 and 40), odd tile counts, GQA group of 3, V = 49 152"""
+    cfg_g = cz.LlamaConfig(49152, 960, 6, 15, 5, 2560, 8192, 100000.0, 1e-5)
+    cfg_o = czo.LlamaConfig(49152, 960, 6, 15, 5, 2560, 8192, 100000.0, 1e-5)
+    g = cz.Session("smollm", cfg_g, seed=77, embed_std=0.02, max_streams=3)
+    o = czo.SmolLmSession(cfg_o, seed=77, embed_std=0.02)
+    rng = np.random.default_rng(8)
+    toks = rng.integers(0, 49152, 700).astype(np.uint32)
+    _eq(g.reprime_with_history_and_get_last_logits_tensor(toks[:1]), o.reprime_logits(toks[:1]), "bos step")
+    for i, t in enumerate(toks[1:4]):
+        _eq(g.step_logits_tensor(t), o.step_logits(t), f"step {i}")
+    _eq(g.reprime_with_history_and_get_last_logits_tensor(toks[:130]), o.reprime_logits(toks[:130]), "reprime(130)")
+    ids = np.concatenate([[0], toks[:40]]).astype(np.uint32)
+    payload, clo, chi, zw = o.encode_tokens(ids)
+    lo, hi = g.encode_tokens(ids)
+    assert np.array_equal(lo, clo) and np.array_equal(hi, chi) and cz.ac_encode_pairs(lo, hi)[0] == payload
+    # three ragged streams in lock-step, one of them long enough to re-prime (GPU round trip; the oracle already pinned the pairs above)
+    streams = [np.concatenate([[0], toks[:n]]).astype(np.uint32) for n in (40, 600, 7)]
+    pays = [cz.ac_encode_pairs(*g.encode_tokens(s_))[0] for s_ in streams]
+    outs = g.decode_tokens_batch(pays, [s_.size - 1 for s_ in streams])
+    for s_, out in zip(streams, outs):
+        assert np.array_equal(s_, out)
+    g.close(); o.close()
+
+
 def test_decode_paths_agree_graph_eager_v1(cz, czo, tiny_pair):
     """hipGraph replay, eager fast kernels and the general (v1) kernels must decode identical ids"""
     g, o = tiny_pair
