@@ -143,7 +143,8 @@ class _Model:
                 self.model_hash = cz.blake3_16(f"synthetic-rwkv7-0.1b:{args.synthetic}".encode())
                 self.repr = b"synthetic"
             else:
-                self.sess = cz.Session("rwkv7", cz.rwkv7_0b1_config(), weight_paths=[args.rwkv_model], device=args.device, max_streams=1)
+                # Rwkv7Session::load(model_path, config_path, device) (src/models.rs:132-146): the config file decides the shape
+                self.sess = cz.Session("rwkv7", None, weight_paths=[args.rwkv_model], config_path=args.rwkv_config, device=args.device, max_streams=1)
                 self.model_hash = _hash_file(args.rwkv_model)                          # :1822
                 self.repr = os.path.basename(args.rwkv_model).encode()
             self.vocab = self.sess.vocab_size()

@@ -252,8 +252,24 @@ static int pad64(int k) { return (k + 63) / 64 * 64; }
 cz_status cz_rwkv7_build(cz_session* s, const cz_model_desc* desc) {
     Rwkv7Model* m = new Rwkv7Model();
     s->rwkv = m;
-    if (desc->config_path) { cz_set_error("rwkv7: config.json parsing is not wired yet; pass cz_rwkv7_config"); return CZ_ERR_UNSUPPORTED; }
-    m->cfg = desc->rwkv;
+    if (desc->config_path) {                                     // candle_rwkv7 Config (rwkv7.rs:7-32; defaults :27-32, ffn :406)
+        FILE* f = fopen(desc->config_path, "rb");
+        if (!f) { cz_set_error("cannot open %s", desc->config_path); return CZ_ERR_IO; }
+        std::string txt; char buf[4096]; size_t n;
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) txt.append(buf, n);
+        fclose(f);
+        JsonValue root; std::string err;
+        if (!cz_json_parse(txt.data(), txt.size(), &root, &err) || root.kind != JsonValue::Obj) { cz_set_error("failed to parse %s as an RWKV7 config: %s", desc->config_path, err.c_str()); return CZ_ERR_IO; }
+        auto num = [&](const char* k, double def) { const JsonValue* v = root.get(k); return v && v->kind == JsonValue::Num ? v->num : def; };
+        cz_rwkv7_config& c = m->cfg;
+        c.vocab = (int)num("vocab_size", 0); c.hidden = (int)num("hidden_size", 0); c.n_layers = (int)num("num_hidden_layers", 0);
+        c.head_dim = (int)num("head_dim", num("head_size", 0));
+        c.d_ffn = (int)num("intermediate_size", 4.0 * c.hidden);
+        c.a_rank = (int)num("a_low_rank_dim", 64); c.decay_rank = (int)num("decay_low_rank_dim", 64);
+        c.v_rank = (int)num("v_low_rank_dim", 32); c.gate_rank = (int)num("gate_low_rank_dim", 128);
+        c.norm_eps = (float)num("norm_eps", 1e-5);
+        if (c.vocab <= 0 || c.hidden <= 0 || c.n_layers <= 0 || c.head_dim <= 0) { cz_set_error("%s: vocab_size / hidden_size / num_hidden_layers / head_dim are required", desc->config_path); return CZ_ERR_IO; }
+    } else m->cfg = desc->rwkv;
     const cz_rwkv7_config& c = m->cfg;
     if (c.head_dim != 64 || c.hidden % 64 || c.hidden > 1024 || c.vocab % 32 || c.d_ffn % 64 || c.n_layers <= 0 || c.a_rank > 64 || c.decay_rank > 64 ||
         c.v_rank > 64 || c.gate_rank > 128 || c.a_rank % 32 || c.decay_rank % 32 || c.v_rank % 32 || c.gate_rank % 32) {
