@@ -36,7 +36,7 @@ class Rwkv7Config(C.Structure):
 class ModelDesc(C.Structure):
     _fields_ = [("backend", C.c_int), ("weight_paths", C.POINTER(C.c_char_p)), ("n_weight_paths", C.c_size_t),
                 ("config_path", C.c_char_p), ("synthetic_seed", C.c_uint64), ("synthetic_embed_std", C.c_float),
-                ("llama", LlamaConfig), ("rwkv", Rwkv7Config), ("max_streams", C.c_uint32)]
+                ("llama", LlamaConfig), ("rwkv", Rwkv7Config), ("max_streams", C.c_uint32), ("round_f32_weights_to_bf16", C.c_uint32)]
 
 
 class Header(C.Structure):
@@ -149,7 +149,7 @@ class Session:
     """mirror of `trait LanguageModelSession` (src/models.rs:28-33) + the fused encode/decode loops"""
 
     def __init__(self, backend="smollm", config=None, weight_paths=(), config_path=None, seed=0x5EED, embed_std=0.02,
-                 device=0, max_streams=64):
+                 device=0, max_streams=64, round_f32_weights_to_bf16=False):
         L = lib()
         d = ModelDesc()
         d.backend = {"smollm": BACKEND_SMOLLM, "rwkv7": BACKEND_RWKV7}[backend.lower()]     # --backend (src/main.rs:1799)
@@ -161,6 +161,7 @@ class Session:
         d.n_weight_paths = len(self._paths)
         d.config_path = config_path.encode() if config_path else None
         d.synthetic_seed, d.synthetic_embed_std, d.max_streams = seed, embed_std, max_streams
+        d.round_f32_weights_to_bf16 = 1 if round_f32_weights_to_bf16 else 0
         if d.backend == BACKEND_SMOLLM:
             d.llama = config if config is not None else smollm2_135m_config()
         else:

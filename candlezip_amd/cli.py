@@ -44,6 +44,9 @@ def build_parser():
     p.add_argument("--context", type=int, default=512)                               # :68-69
     p.add_argument("--reprime-interval", type=int, default=512)                      # :71-72
     p.add_argument("--force-mismatch", action="store_true")                          # :122-123
+    p.add_argument("--round-weights-to-bf16", action="store_true",
+                   help="accept an F32 checkpoint whose values bf16 cannot hold (converted RWKV7 weights) by rounding them: a slightly "
+                        "different model than the reference's f32 one; without this flag such a checkpoint is refused")
     p.add_argument("--reuse", action="store_true")                                   # :126-127 (agent cache; no effect without the agent)
     for f in _AGENT_FLAGS:
         p.add_argument(f, action="store_true")
@@ -121,7 +124,8 @@ class _Model:
                 paths = [args.model] if os.path.isfile(args.model) else sorted(
                     os.path.join(args.model, f) for f in os.listdir(args.model) if f.endswith(".safetensors"))
                 cfgp = args.config or os.path.join(os.path.dirname(paths[0]), "config.json")
-                self.sess = cz.Session("smollm", None, weight_paths=paths, config_path=cfgp, device=args.device, max_streams=1)
+                self.sess = cz.Session("smollm", None, weight_paths=paths, config_path=cfgp, device=args.device, max_streams=1,
+                                       round_f32_weights_to_bf16=args.round_weights_to_bf16)
                 self.model_hash = _hash_files(paths)                                   # blake3_files_bin16 (:1810)
                 self.repr = os.path.basename(paths[0]).encode() if len(paths) == 1 else b"model.safetensors.index.json"
             if args.tokenizer:
@@ -144,7 +148,8 @@ class _Model:
                 self.repr = b"synthetic"
             else:
                 # Rwkv7Session::load(model_path, config_path, device) (src/models.rs:132-146): the config file decides the shape
-                self.sess = cz.Session("rwkv7", None, weight_paths=[args.rwkv_model], config_path=args.rwkv_config, device=args.device, max_streams=1)
+                self.sess = cz.Session("rwkv7", None, weight_paths=[args.rwkv_model], config_path=args.rwkv_config, device=args.device, max_streams=1,
+                                       round_f32_weights_to_bf16=args.round_weights_to_bf16)
                 self.model_hash = _hash_file(args.rwkv_model)                          # :1822
                 self.repr = os.path.basename(args.rwkv_model).encode()
             self.vocab = self.sess.vocab_size()

@@ -31,6 +31,12 @@ struct LlamaModel {
     size_t param_count = 0;
 };
 
+// f32 bits -> f32 bits of the nearest-even bf16 (NaN stays NaN)
+static inline uint32_t cz_f32_bits_round_bf16(uint32_t u) {
+    if ((u & 0x7f800000u) == 0x7f800000u) return u & 0xffff0000u ? (u | 0x00400000u) & 0xffff0000u : u & 0xffff0000u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+}
+
 struct Rwkv7Model;   // rwkv7.hip
 
 struct cz_session {
@@ -38,6 +44,7 @@ struct cz_session {
     int device = 0;
     hipStream_t stream = nullptr;
     uint64_t seed = 0;
+    bool round_f32 = false;            // cz_model_desc.round_f32_weights_to_bf16
     LlamaModel llama;
     Rwkv7Model* rwkv = nullptr;
     // packed-row work buffers

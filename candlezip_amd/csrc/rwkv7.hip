@@ -305,7 +305,8 @@ cz_status cz_rwkv7_build(cz_session* s, const cz_model_desc* desc) {
                 const uint32_t* src = (const uint32_t*)t.data;
                 for (size_t i = 0; i < numel; ++i) {
                     uint32_t u; memcpy(&u, src + i, 4);
-                    if (u & 0xffffu) { cz_set_error("tensor %s is F32 with values that are not bf16-representable (unsupported)", name.c_str()); return CZ_ERR_UNSUPPORTED; }
+                    if ((u & 0xffffu) && !s->round_f32) { cz_set_error("tensor %s is F32 with values that are not bf16-representable (unsupported; see cz_model_desc.round_f32_weights_to_bf16)", name.c_str()); return CZ_ERR_UNSUPPORTED; }
+                    if (u & 0xffffu) u = cz_f32_bits_round_bf16(u);
                     h16[i] = (uint16_t)(u >> 16);
                 }
                 HIPCHK(hipMemcpy(dst, h16.data(), numel * 2, hipMemcpyHostToDevice));

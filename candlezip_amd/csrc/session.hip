@@ -130,7 +130,8 @@ static cz_status load_tensor(cz_session* s, std::vector<std::unique_ptr<SafeTens
             const uint32_t* src = (const uint32_t*)t.data;
             for (size_t i = 0; i < numel; ++i) {
                 uint32_t u; memcpy(&u, src + i, 4);
-                if (u & 0xffffu) { cz_set_error("tensor %s is F32 with values that are not bf16-representable (unsupported)", name.c_str()); return CZ_ERR_UNSUPPORTED; }
+                if ((u & 0xffffu) && !s->round_f32) { cz_set_error("tensor %s is F32 with values that are not bf16-representable (unsupported; see cz_model_desc.round_f32_weights_to_bf16)", name.c_str()); return CZ_ERR_UNSUPPORTED; }
+                if (u & 0xffffu) u = cz_f32_bits_round_bf16(u);
                 tmp[i] = (uint16_t)(u >> 16);
             }
             HIPCHK(hipMemcpy(dst, tmp.data(), numel * 2, hipMemcpyHostToDevice));
@@ -718,7 +719,7 @@ extern "C" cz_status cz_session_open(const cz_model_desc* desc, int device_ordin
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device_ordinal));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { cz_set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device_ordinal, prop.gcnArchName); return CZ_ERR_HIP; }
     cz_session* s = new cz_session();
-    s->backend = desc->backend; s->device = device_ordinal; s->seed = desc->synthetic_seed;
+    s->backend = desc->backend; s->device = device_ordinal; s->seed = desc->synthetic_seed; s->round_f32 = desc->round_f32_weights_to_bf16 != 0;
     s->max_streams = desc->max_streams ? (int)desc->max_streams : 64;
     if (s->max_streams > 256) { delete s; cz_set_error("max_streams > 256 is not supported"); return CZ_ERR_ARG; }
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);   // several sessions may capture/replay graphs concurrently

@@ -54,6 +54,10 @@ typedef struct cz_model_desc {
     cz_llama_config llama;
     cz_rwkv7_config rwkv;
     uint32_t max_streams;               /* capacity of the lock-step decode batch (0 => 64, at most 256) */
+    /* Weights live in HBM as bf16.  An F32 tensor whose values bf16 cannot hold (the converted RWKV7 checkpoints) is refused
+     * (CZ_ERR_UNSUPPORTED) unless this is non-zero: then it is rounded to nearest-even bf16 — a slightly different model than the
+     * reference's f32 one (other payloads, still self-consistent between compress and decompress).  Explicit opt-in only. */
+    uint32_t round_f32_weights_to_bf16;
 } cz_model_desc;
 
 typedef struct cz_session cz_session;

@@ -81,6 +81,12 @@ def test_smollm_safetensors_and_config_json(cz, czo, tmp_path):
     with pytest.raises(cz.CandlezipError) as e:
         cz.Session("smollm", None, weight_paths=[str(tmp_path / "f32_full.safetensors")], config_path=str(tmp_path / "config.json"))
     assert "not bf16-representable" in str(e.value)           # refused loudly, never rounded silently
+    # ... unless the caller opts in: round-to-nearest-even bf16 (here the perturbed norm weights round back to the original bits or one ulp)
+    g = cz.Session("smollm", None, weight_paths=[str(tmp_path / "f32_full.safetensors")], config_path=str(tmp_path / "config.json"), max_streams=1,
+                   round_f32_weights_to_bf16=True)
+    lo2, hi2 = g.encode_tokens(ids)
+    assert np.array_equal(g.decode_tokens(cz.ac_encode_pairs(lo2, hi2)[0], 200), ids)     # self-consistent whatever the rounding did
+    g.close()
     o.close()
 
 
