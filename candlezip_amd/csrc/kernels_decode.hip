@@ -366,7 +366,7 @@ hipError_t cz_launch_dec_gemm_swiglu(hipStream_t st, const float* A, int lda, co
 typedef __attribute__((address_space(1))) const float gfloat;     // K/V pointers come out of a descriptor in memory: tell the
                                                                   // compiler they are global (global_load, not flat_load)
 template <int rep>   // query heads per kv head: compile-time so that the per-head code carries no branches
-__global__ __launch_bounds__(DA_THREADS) void dec_attn_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
+__global__ __launch_bounds__(DA_THREADS, 4) void dec_attn_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
                                                               const cz_seq_desc* __restrict__ descs, int n_heads, int n_kv, int s_stride,
                                                               size_t kv_off, const int* __restrict__ pos_dev) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -396,26 +396,31 @@ __global__ __launch_bounds__(DA_THREADS) void dec_attn_kernel(const float* __res
             const int j = c * 64 + lane;
             if (j < nk) {
                 float s[DA_MAXREP] = {0.0f, 0.0f, 0.0f, 0.0f};
-                // transposed cache: for every d the 64 lanes (keys) read 256 contiguous bytes; all 64 loads are issued up front
-                float kreg[64];
-                if (sd.kt_stride) {
+                // transposed cache: for every d the 64 lanes (keys) read 256 contiguous bytes.  Four real (not unrolled) rounds of 16 d keep
+                // the kernel under 128 VGPRs -> two blocks per CU: one block's softmax phase overlaps the other's loads, and the 384 blocks
+                // of a 128-stream step are resident at once instead of running in one and a half rounds
+#pragma unroll 1
+                for (int g = 0; g < 4; ++g) {
+                    float kreg[16];
+                    if (sd.kt_stride) {
 #pragma unroll
-                    for (int dd = 0; dd < 64; ++dd) kreg[dd] = Kb[(size_t)dd * sd.kt_stride + j];
-                } else {
-                    const __attribute__((address_space(1))) f32x4* kr = (const __attribute__((address_space(1))) f32x4*)(Kb + (size_t)j * sd.kv_stride);
+                        for (int dd = 0; dd < 16; ++dd) kreg[dd] = Kb[(size_t)(g * 16 + dd) * sd.kt_stride + j];
+                    } else {
+                        const __attribute__((address_space(1))) f32x4* kr = (const __attribute__((address_space(1))) f32x4*)(Kb + (size_t)j * sd.kv_stride + g * 16);
 #pragma unroll
-                    for (int q4 = 0; q4 < 16; ++q4) { const f32x4 t4 = kr[q4]; kreg[4 * q4] = t4[0]; kreg[4 * q4 + 1] = t4[1]; kreg[4 * q4 + 2] = t4[2]; kreg[4 * q4 + 3] = t4[3]; }
-                }
+                        for (int q4 = 0; q4 < 4; ++q4) { const f32x4 t4 = kr[q4]; kreg[4 * q4] = t4[0]; kreg[4 * q4 + 1] = t4[1]; kreg[4 * q4 + 2] = t4[2]; kreg[4 * q4 + 3] = t4[3]; }
+                    }
 #pragma unroll
-                for (int q4 = 0; q4 < 16; ++q4) {
-                    const f32x4 kv = f32x4{kreg[4 * q4], kreg[4 * q4 + 1], kreg[4 * q4 + 2], kreg[4 * q4 + 3]};
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 kv = f32x4{kreg[4 * q4], kreg[4 * q4 + 1], kreg[4 * q4 + 2], kreg[4 * q4 + 3]};
 #pragma unroll
-                    for (int h = 0; h < DA_MAXREP; ++h)
-                        if (h < rep) {
-                            const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + h * 64 + q4 * 4);
-                            s[h] = cz_fma(qv[0], kv[0], s[h]); s[h] = cz_fma(qv[1], kv[1], s[h]);
-                            s[h] = cz_fma(qv[2], kv[2], s[h]); s[h] = cz_fma(qv[3], kv[3], s[h]);
-                        }
+                        for (int h = 0; h < DA_MAXREP; ++h)
+                            if (h < rep) {
+                                const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + h * 64 + g * 16 + q4 * 4);
+                                s[h] = cz_fma(qv[0], kv[0], s[h]); s[h] = cz_fma(qv[1], kv[1], s[h]);
+                                s[h] = cz_fma(qv[2], kv[2], s[h]); s[h] = cz_fma(qv[3], kv[3], s[h]);
+                            }
+                    }
                 }
 #pragma unroll
                 for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) { sc[i][h] = s[h] * 0.125f; lm[h] = sc[i][h] > lm[h] ? sc[i][h] : lm[h]; }
@@ -489,18 +494,26 @@ __global__ __launch_bounds__(DA_THREADS) void dec_attn_kernel(const float* __res
             float acc[DA_MAXREP] = {0.0f, 0.0f, 0.0f, 0.0f};
             const int jend = nk - c * 64 < 64 ? nk - c * 64 : 64;
             gfloat* vp = Vb + (size_t)(c * 64) * sd.kv_stride + lane;
-            float vreg[64];                               // the whole 64-key slab of this lane's column: all loads in flight at once
-            // unconditional loads (row index clamped) + select afterwards: a per-element "load or 0" on a runtime bound makes hipcc
-            // branch around every load and wait for each one (64 serialized round trips per chunk)
+            // the 64-key slab of this lane's column in four real rounds of 16 keys (register budget, see phase 1).  Unconditional loads (row
+            // index clamped) + select afterwards: a per-element "load or 0" on a runtime bound makes hipcc branch around every load and wait
+            // for each one.  Keys past nk have p == 0 (exp(-inf)) and v == 0: fma(0, 0, acc) == acc, so the chain needs no guard.
+#pragma unroll 1
+            for (int g = 0; g < 4; ++g) {
+                float vreg[16];
 #pragma unroll
-            for (int j = 0; j < 64; ++j) { const int jj = j < jend ? j : jend - 1; vreg[j] = vp[(size_t)jj * sd.kv_stride]; }
+                for (int j = 0; j < 16; ++j) { const int jx = g * 16 + j; const int jj = jx < jend ? jx : jend - 1; vreg[j] = vp[(size_t)jj * sd.kv_stride]; }
 #pragma unroll
-            for (int j = 0; j < 64; ++j) vreg[j] = j < jend ? vreg[j] : 0.0f;
-            // keys past nk have p == 0 (exp(-inf)) and v == 0: fma(0, 0, acc) == acc, so the chain below needs no guard
+                for (int j = 0; j < 16; ++j) vreg[j] = g * 16 + j < jend ? vreg[j] : 0.0f;
 #pragma unroll
-            for (int j = 0; j < 64; ++j) {
+                for (int j4 = 0; j4 < 4; ++j4) {
+                    f32x4 pv[DA_MAXREP];
 #pragma unroll
-                for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) acc[h] = cz_fma(S[h * s_stride + c * 64 + j], vreg[j], acc[h]);
+                    for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) pv[h] = *reinterpret_cast<const f32x4*>(S + h * s_stride + c * 64 + g * 16 + 4 * j4);   // 4 keys per LDS read
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) acc[h] = cz_fma(pv[h][u], vreg[4 * j4 + u], acc[h]);
+                }
             }
 #pragma unroll
             for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) part[(c * DA_MAXREP + h) * 64 + lane] = acc[h];
