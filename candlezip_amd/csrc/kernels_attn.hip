@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #define V2_KS 68
 #define V2_VS 80
 template <int REP, int NI>
-__global__ __launch_bounds__(256, 1) void attention_v2_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
+__global__ __launch_bounds__(256, (REP * NI <= 48 ? 2 : 1)) void attention_v2_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
                                                               const cz_seq_desc* __restrict__ descs, size_t kv_off, const int* __restrict__ pos_dev) {
     __shared__ __attribute__((aligned(16))) float stage[64 * V2_VS];      // K tile (stride 68) or V tile (stride 80)
     __shared__ __attribute__((aligned(16))) float Et[REP * 16 * V2_KS];   // e / p tile of the current chunk, [slot][key]
