@@ -27,7 +27,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_bf16w_kernel(const float* __restrict__ A, int lda,
+__global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restrict__ A, int lda,
                                                          const uint16_t* __restrict__ W, float* __restrict__ C, int ldc,
                                                          const float* __restrict__ R, int ldr, int M, int N, int K,
                                                          int nbx, int nblocks) {
