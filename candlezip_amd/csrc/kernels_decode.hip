@@ -273,12 +273,13 @@ static hipError_t dec_gemm_launch_mt(hipStream_t st, const dec_gemm_args& a, int
     return hipGetLastError();
 }
 int g_dec_grid_target = 384;     // tuning knob (cz_debug_set "dec_grid_target")
+int g_dec_mt_max = 8;            // tuning knob (cz_debug_set "dec_mt_max"): most 16-row tiles per block
 template <int EPI, int NORM>
 static hipError_t dec_gemm_launch_n(hipStream_t st, const dec_gemm_args& a, int gx) {
     // row tiles per block: keep the grid near one wave of blocks (<= ~384) while it still has >= 64 of them
     const int mt_all = (a.M + 15) / 16;
     int mt = 1;
-    while (mt < 8 && mt < mt_all && (long)gx * ((mt_all + mt - 1) / mt) > g_dec_grid_target) mt *= 2;
+    while (mt < g_dec_mt_max && mt < mt_all && (long)gx * ((mt_all + mt - 1) / mt) > g_dec_grid_target) mt *= 2;
     switch (mt) {
         case 1: return dec_gemm_launch_mt<EPI, NORM, 1>(st, a, gx);
         case 2: return dec_gemm_launch_mt<EPI, NORM, 2>(st, a, gx);

@@ -26,6 +26,7 @@
 extern int g_attn_v1;
 extern int g_dec_grid_target;
 extern int g_dec_nw_cap;
+extern int g_dec_mt_max;
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t _e = (expr);                                                                        \
@@ -944,6 +945,7 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "kv_ctx_cap")) { if (s->kvcache) { cz_set_error("kv_ctx_cap must be set before the first step / decode"); return CZ_ERR_STATE; } s->kv_ctx_cap = (int)value; }
     else if (!strcmp(key, "probe_launch")) s->probe_launch = (int)value;
     else if (!strcmp(key, "dec_grid_target")) g_dec_grid_target = (int)value;
+    else if (!strcmp(key, "dec_mt_max")) g_dec_mt_max = (int)value >= 8 ? 8 : ((int)value >= 4 ? 4 : ((int)value >= 2 ? 2 : 1));
     else if (!strcmp(key, "dec_nw_cap")) g_dec_nw_cap = (int)value < 4 ? 4 : ((int)value > 12 ? 12 : (int)value);
     else { cz_set_error("unknown debug key %s", key); return CZ_ERR_ARG; }
     return CZ_OK;

@@ -10,6 +10,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 cfg = cz.smollm2_135m_config()
 s = cz.Session("smollm", cfg, seed=0x5EED, embed_std=0.02, max_streams=B)
+for kv in sys.argv[3:]:                      # extra debug knobs: key=value
+    k, v = kv.split("="); s.debug_set(k, int(v))
 rng = np.random.default_rng(0)
 streams = [np.concatenate([[0], rng.integers(0, cfg.vocab, T)]).astype(np.uint32) for _ in range(B)]
 pairs = s.encode_tokens_batch(streams)
