@@ -50,7 +50,7 @@ FAMILY_KERNELS = {
 }
 
 
-def pmc_traffic(family):
+def pmc_traffic(family, tag="pmc"):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc passes (profiles/r*_pmc_*_pmc.json, made by
     tools/prof_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same bench in eager mode).  FETCH_SIZE / WRITE_SIZE
     are in KiB; on gfx950 FETCH_SIZE counts 128-B requests of wide coalesced reads at 64 B, so it is doubled (MI355X_MICROARCH.md,
@@ -59,7 +59,7 @@ def pmc_traffic(family):
     here = os.path.dirname(os.path.abspath(__file__))
     tot = 0.0; notes = []
     for counter, scale in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
-        files = sorted(glob.glob(os.path.join(here, "profiles", f"r*_pmc_{counter}_pmc.json")))
+        files = sorted(glob.glob(os.path.join(here, "profiles", f"r*_{tag}_{counter}_pmc.json")))
         if not files:
             notes.append(f"{counter}: no pass committed")
             continue
@@ -301,7 +301,7 @@ def main():
         both = {k: prof_timed.get("gemm_bf16w_f32_mfma", zero)[k] + prof_timed.get("gemm_bf16w_f32_mfma_n64", zero)[k] for k in zero}
         if "dec_attention" in prof_ctx:
             roof_ctx = roof_of("dec_attention", prof_ctx["dec_attention"])
-            roof_ctx["traffic"] = None; roof_ctx["traffic_source"] = "not collected at this size (rocprofv3 --pmc crashes in its dispatch interception, DESIGN.md §9)"
+            roof_ctx["traffic"], roof_ctx["traffic_source"] = pmc_traffic("dec_attention", "pmc1536")
             roof_ctx["measured_in"] = "eager pass inside bench.py, 128 streams x 1536 tokens (contexts up to 1023 keys, mean 597), HIP events, one decode lane"
         else:
             roof_ctx = None
