@@ -405,7 +405,7 @@ __global__ __launch_bounds__(DA_THREADS, 4) void dec_attn_kernel(const float* __
                     float kreg[16];
                     if (sd.kt_stride) {
 #pragma unroll
-                        for (int dd = 0; dd < 16; ++dd) kreg[dd] = Kb[(size_t)(g * 16 + dd) * sd.kt_stride + j];
+                        for (int dd = 0; dd < 16; ++dd) kreg[dd] = __builtin_nontemporal_load(Kb + (size_t)(g * 16 + dd) * sd.kt_stride + j);   // streamed once per step: keep it out of the way of the weights
                     } else {
                         const __attribute__((address_space(1))) f32x4* kr = (const __attribute__((address_space(1))) f32x4*)(Kb + (size_t)j * sd.kv_stride + g * 16);
 #pragma unroll
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(DA_THREADS, 4) void dec_attn_kernel(const float* __
             for (int g = 0; g < 4; ++g) {
                 float vreg[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) { const int jx = g * 16 + j; const int jj = jx < jend ? jx : jend - 1; vreg[j] = vp[(size_t)jj * sd.kv_stride]; }
+                for (int j = 0; j < 16; ++j) { const int jx = g * 16 + j; const int jj = jx < jend ? jx : jend - 1; vreg[j] = __builtin_nontemporal_load(vp + (size_t)jj * sd.kv_stride); }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) vreg[j] = g * 16 + j < jend ? vreg[j] : 0.0f;
 #pragma unroll
