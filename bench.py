@@ -177,7 +177,7 @@ def main():
     ap.add_argument("--dec-grid-target", type=int, default=0, help="tuning: blocks per decode GEMM launch (0 = library default)")
     ap.add_argument("--lane-streams", type=int, default=128, help="streams per lock-step group")
     ap.add_argument("--warmup-tokens", type=int, default=1100, help="tokens/stream of a warmup step")
-    ap.add_argument("--profile-tokens", type=int, default=600, help="tokens/stream of the untimed per-family profiling pass")
+    ap.add_argument("--profile-tokens", type=int, default=1536, help="tokens/stream of the untimed per-family profiling pass")
     ap.add_argument("--tokens", type=int, default=0,
                     help="tokens per stream and step; default: one 64 KiB enwik8 sample (17408 tokens) spread over the K steps, "
                          "i.e. max(2048, 17408 / K rounded up to 512), so that the whole run stays within minutes for any K")
@@ -261,13 +261,6 @@ def main():
     if args.profile_tokens > 0:
         self_test_step(cz, sess, short, args.context, args.reprime_interval)
     prof_all = sess.profile_read()
-    # the dominant decode kernel once more over the workload's own context sawtooth (511 -> 1023 keys once a stream is past its first
-    # re-prime): the 600-token pass above stops at 600 keys, where the kernel's fixed cost weighs twice as much
-    prof_ctx = {}
-    if args.profile_tokens > 0 and args.tokens >= 1536:
-        sess.profile_enable(True, only=["dec_attention"])
-        self_test_step(cz, sess, [s[:1537] for s in streams[: min(args.streams, args.lane_streams)]], args.context, args.reprime_interval)
-        prof_ctx = sess.profile_read()
     sess.profile_enable(False)
     dominant = max(prof_all, key=lambda k: prof_all[k]["total_ms"]) if prof_all else "gemm_bf16w_f32_mfma"
     if dist is not None:
@@ -289,22 +282,16 @@ def main():
             else:
                 ach = st["bytes"] / (st["total_ms"] * 1e-3) / 1e9 if st["total_ms"] else 0.0
                 r = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5)}
-            traffic, tnote = pmc_traffic(name)
+            traffic, tnote = pmc_traffic(name, "pmc1536" if args.profile_tokens == 1536 else "pmc")
             r.update({"traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": tnote,
                       "algorithmic_per_launch": round((st["flops"] if r["bound"] == "mfma" else st["bytes"]) / max(st["launches"], 1)), "kernel": name, "launches": st["launches"], "avg_launch_us": round(1e3 * st["total_ms"] / max(st["launches"], 1), 3)})
             return r
         roof = roof_of(dominant, prof_all.get(dominant, {"launches": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0}))
-        roof["measured_in"] = (f"eager per-family pass inside bench.py ({len(short)} streams x {args.profile_tokens} tokens, one decode lane); "
-                               "the timed region replays hipGraphs on concurrent lanes")
+        roof["measured_in"] = (f"eager per-family pass inside bench.py ({len(short)} streams x {args.profile_tokens} tokens: the workload's own context "
+                               "sawtooth, up to 1023 keys; one decode lane); the timed region replays hipGraphs on concurrent lanes")
         roof["families_ms_profile_pass"] = {k: round(v["total_ms"], 2) for k, v in prof_all.items()}
         zero = {"launches": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0}
         both = {k: prof_timed.get("gemm_bf16w_f32_mfma", zero)[k] + prof_timed.get("gemm_bf16w_f32_mfma_n64", zero)[k] for k in zero}
-        if "dec_attention" in prof_ctx:
-            roof_ctx = roof_of("dec_attention", prof_ctx["dec_attention"])
-            roof_ctx["traffic"], roof_ctx["traffic_source"] = pmc_traffic("dec_attention", "pmc1536")
-            roof_ctx["measured_in"] = "eager pass inside bench.py, 128 streams x 1536 tokens (contexts up to 1023 keys, mean 597), HIP events, one decode lane"
-        else:
-            roof_ctx = None
         roof_gemm = roof_of("gemm_bf16w_f32_mfma", both)
         roof_gemm["kernel"] = "gemm_bf16w_kernel<128,128> + <128,64> (both tile shapes of the big-M GEMM)"
         roof_gemm["traffic"] = None; roof_gemm["traffic_source"] = "see roofline (per-kernel PMC numbers are in profiles/)"
@@ -325,7 +312,6 @@ def main():
             "compress_tokens_per_s_rank0": round(tok / te, 1) if te else None,
             "decompress_tokens_per_s_rank0": round(tok / td, 1) if td else None,
             "roofline": roof,
-            "roofline_at_workload_contexts": roof_ctx,
             "roofline_mfma_gemm": roof_gemm,
         }
         if world == 1 and args.cpu_sample > 0 and not args.tiny:

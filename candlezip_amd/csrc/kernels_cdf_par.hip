@@ -249,7 +249,9 @@ __device__ __forceinline__ double exact_seq_sum(XF xf, double csum, int cnt, int
 // MODE = 1: RWKV with literals (softmax_pdf_floor + combined_pdf_with_literals + the inline quantiser, src/main.rs:758-782,
 //           2303-2325): FOUR sequential f64 chains — sum of exps (V), sum of floored probabilities (V), sum of the scaled
 //           distribution with its 256 literal entries (V+256), running cdf (V+256) — each evaluated exactly in parallel.
-template <int DECODE, int MODE, int LMAX>
+// FULL: the alphabet fills the block exactly (V == T_PAR * LMAX, e.g. 49 152 = 1024 x 48): every `k < cnt` guard folds away, and with
+// it the exec masks the unrolled loops would otherwise keep alive (hundreds of spilled SGPRs, ~40 MB of scratch traffic per launch)
+template <int DECODE, int MODE, int LMAX, bool FULL>
 __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict__ logits, int ld, int rows, int V,
                                                         const uint32_t* __restrict__ sym, uint32_t* __restrict__ c_lo,
                                                         uint32_t* __restrict__ c_hi, double* __restrict__ scratch_all,
@@ -264,9 +266,10 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
     double* scratch = scratch_all + (size_t)blockIdx.x * n;
     int L = (n + T_PAR - 1) / T_PAR;
     if (L >= 8) L = (L + 3) & ~3;                                  // chunks start on 16-B boundaries: 4 logits per load
+    if (FULL) L = LMAX;
     const int first = tid * L;
-    const int cntA = first >= V ? 0 : (V - first < L ? V - first : L);       // owned vocabulary entries (terms of the chains over V)
-    const int cnt = first >= n ? 0 : (n - first < L ? n - first : L);        // owned symbols (vocabulary, then literals)
+    const int cntA = FULL ? LMAX : (first >= V ? 0 : (V - first < L ? V - first : L));       // owned vocabulary entries (terms of the chains over V)
+    const int cnt = FULL ? LMAX : (first >= n ? 0 : (n - first < L ? n - first : L));        // owned symbols (vocabulary, then literals)
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
         cz_dec_state d;
         if (DECODE) {
@@ -525,11 +528,14 @@ hipError_t cz_launch_cdf_pairs(hipStream_t st, const float* logits, int ld, cons
     if (!cz_cdf_par_supported(vocab, mode)) return out_step_dev ? hipErrorInvalidValue : cz_launch_cdf_pairs_serial(st, logits, ld, sym, c_lo, c_hi, rows, vocab, mode);
     if (!g_scratch) return hipErrorInvalidValue;
     const int grid = rows < CZ_CDF_PAR_MAX_GRID ? rows : CZ_CDF_PAR_MAX_GRID;
-    if (mode == 0)
-        hipLaunchKernelGGL((cdf_par_kernel<0, 0, LMAX_SMOLLM>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, c_lo, c_hi, g_scratch, nullptr, nullptr,
+    if (mode == 0 && vocab == T_PAR * LMAX_SMOLLM)
+        hipLaunchKernelGGL((cdf_par_kernel<0, 0, LMAX_SMOLLM, true>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, c_lo, c_hi, g_scratch, nullptr, nullptr,
+                           0ull, fallback_count, out_step_dev);
+    else if (mode == 0)
+        hipLaunchKernelGGL((cdf_par_kernel<0, 0, LMAX_SMOLLM, false>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, c_lo, c_hi, g_scratch, nullptr, nullptr,
                            0ull, fallback_count, out_step_dev);
     else
-        hipLaunchKernelGGL((cdf_par_kernel<0, 1, LMAX_RWKV>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, c_lo, c_hi, g_scratch, nullptr, nullptr,
+        hipLaunchKernelGGL((cdf_par_kernel<0, 1, LMAX_RWKV, false>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, c_lo, c_hi, g_scratch, nullptr, nullptr,
                            0ull, fallback_count, out_step_dev);
     return hipGetLastError();
 }
@@ -539,11 +545,14 @@ hipError_t cz_launch_decode_symbol(hipStream_t st, const float* logits, int ld, 
     if (nstreams <= 0) return hipSuccess;
     if (!cz_cdf_par_supported(vocab, mode)) return cz_launch_decode_symbol_serial(st, logits, ld, st_arr, sym_out, nstreams, vocab, mode, i, step_dev);
     if (!g_scratch || nstreams > CZ_CDF_PAR_MAX_GRID) return hipErrorInvalidValue;
-    if (mode == 0)
-        hipLaunchKernelGGL((cdf_par_kernel<1, 0, LMAX_SMOLLM>), dim3(nstreams), dim3(T_PAR), 0, st, logits, ld, nstreams, vocab, nullptr, nullptr, nullptr, g_scratch,
+    if (mode == 0 && vocab == T_PAR * LMAX_SMOLLM)
+        hipLaunchKernelGGL((cdf_par_kernel<1, 0, LMAX_SMOLLM, true>), dim3(nstreams), dim3(T_PAR), 0, st, logits, ld, nstreams, vocab, nullptr, nullptr, nullptr, g_scratch,
+                           st_arr, sym_out, i, fallback_count, step_dev);
+    else if (mode == 0)
+        hipLaunchKernelGGL((cdf_par_kernel<1, 0, LMAX_SMOLLM, false>), dim3(nstreams), dim3(T_PAR), 0, st, logits, ld, nstreams, vocab, nullptr, nullptr, nullptr, g_scratch,
                            st_arr, sym_out, i, fallback_count, step_dev);
     else
-        hipLaunchKernelGGL((cdf_par_kernel<1, 1, LMAX_RWKV>), dim3(nstreams), dim3(T_PAR), 0, st, logits, ld, nstreams, vocab, nullptr, nullptr, nullptr, g_scratch,
+        hipLaunchKernelGGL((cdf_par_kernel<1, 1, LMAX_RWKV, false>), dim3(nstreams), dim3(T_PAR), 0, st, logits, ld, nstreams, vocab, nullptr, nullptr, nullptr, g_scratch,
                            st_arr, sym_out, i, fallback_count, step_dev);
     return hipGetLastError();
 }
