@@ -57,7 +57,7 @@ struct cz_session {
     double* cdf_scratch = nullptr;      // spill rows of the exact-parallel CDF kernel (cz_cdf_par_scratch_bytes)
     // decode lanes: independent lock-step groups replayed concurrently on their own HIP streams (share the weights)
     std::vector<cz_session*> lanes; bool is_lane = false; int max_lanes = 4;
-    cz_session* fork_of = nullptr; int n_forks = 0;   // cz_session_fork: shares the parent's weights, must be closed before it
+    cz_session* fork_of = nullptr; std::vector<cz_session*> forks; bool orphan = false;   // cz_session_fork: a fork shares the parent's weights; closing the parent first orphans it (every call then fails)
     cz_session() {
         DevBuf* all[] = {&tok, &x, &xn, &qkv, &gu, &h, &seqd, &roped, &rowidx, &sym, &clo, &chi, &xl, &logits, &payload, &outids, &decst};
         for (DevBuf* b : all) b->gen = &devbuf_gen;

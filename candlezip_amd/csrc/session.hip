@@ -710,6 +710,10 @@ static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* 
 }
 
 // ------------------------------------------------------------------ C ABI
+static inline bool cz_dead(const cz_session* s) {
+    if (s && s->orphan) { cz_set_error("this session is a fork whose parent (the owner of the weights) was closed"); return true; }
+    return false;
+}
 extern "C" cz_status cz_session_open(const cz_model_desc* desc, int device_ordinal, cz_session** out) {
     if (!desc || !out) { cz_set_error("cz_session_open: null argument"); return CZ_ERR_ARG; }
     *out = nullptr;
@@ -742,8 +746,12 @@ extern "C" cz_status cz_session_open(const cz_model_desc* desc, int device_ordin
 }
 extern "C" void cz_session_close(cz_session* s) {
     if (!s) return;
-    if (s->fork_of) { s->fork_of->n_forks -= 1; }
-    else if (s->n_forks > 0) fprintf(stderr, "candlezip: closing a session that still has %d fork(s): their weights are gone\n", s->n_forks);
+    if (s->fork_of) { auto& v = s->fork_of->forks; v.erase(std::remove(v.begin(), v.end(), s), v.end()); }
+    for (cz_session* f : s->forks) {                                // forks outlive their parent only as husks: no weights, every call fails
+        f->fork_of = nullptr; f->orphan = true;
+        f->llama.blob = f->llama.blob_dec = nullptr; f->llama.rope_cos = f->llama.rope_sin = nullptr;
+    }
+    s->forks.clear();
     hipSetDevice(s->device);
     for (cz_session* l : s->lanes) cz_session_close(l);
     s->lanes.clear();
@@ -767,6 +775,7 @@ extern "C" size_t cz_max_context_length(const cz_session* s) { return s && s->ba
 extern "C" size_t cz_index_pos(const cz_session* s) { return s ? s->index_pos : 0; }
 
 extern "C" cz_status cz_step_logits(cz_session* s, uint32_t token, float* out_logits) {
+    if (cz_dead(s)) return CZ_ERR_STATE;
     if (!s || !out_logits) { cz_set_error("cz_step_logits: null argument"); return CZ_ERR_ARG; }
     HIPCHK(hipSetDevice(s->device));
     if (s->backend == CZ_BACKEND_RWKV7) return cz_rwkv7_step_host(s, token, out_logits);
@@ -781,6 +790,7 @@ extern "C" cz_status cz_step_logits(cz_session* s, uint32_t token, float* out_lo
     return CZ_OK;
 }
 extern "C" cz_status cz_reprime_logits(cz_session* s, const uint32_t* history, size_t n, float* out_logits) {
+    if (cz_dead(s)) return CZ_ERR_STATE;
     if (!s || !out_logits) { cz_set_error("cz_reprime_logits: null argument"); return CZ_ERR_ARG; }
     if (!history || n == 0) { cz_set_error("reprime called with empty history"); return CZ_ERR_ARG; }   // src/models.rs:108 / :164
     HIPCHK(hipSetDevice(s->device));
@@ -846,6 +856,7 @@ static cz_status run_on_lanes(cz_session* s, size_t n_streams, GroupFn group) {
 
 extern "C" cz_status cz_encode_tokens_batch(cz_session* s, size_t n_streams, const uint32_t* const* ids, const size_t* n, uint32_t context,
                                             uint32_t reprime_interval, uint32_t* const* out_c_lo, uint32_t* const* out_c_hi) {
+    if (cz_dead(s)) return CZ_ERR_STATE;
     if (!s || !ids || !n || !out_c_lo || !out_c_hi) { cz_set_error("cz_encode_tokens_batch: null argument"); return CZ_ERR_ARG; }
     HIPCHK(hipSetDevice(s->device));
     if (s->backend == CZ_BACKEND_RWKV7) {                  // RWKV has no re-prime: encode walks the recurrence in lock-step too, one group per lane
@@ -863,6 +874,7 @@ extern "C" cz_status cz_encode_tokens(cz_session* s, const uint32_t* ids, size_t
 extern "C" cz_status cz_decode_tokens_batch(cz_session* s, size_t n_streams, const uint8_t* const* payloads, const size_t* lens,
                                             const size_t* token_counts, uint32_t context_window, uint32_t reprime_interval, uint32_t bos,
                                             uint32_t* const* out_ids) {
+    if (cz_dead(s)) return CZ_ERR_STATE;
     if (!s || !payloads || !lens || !token_counts || !out_ids) { cz_set_error("cz_decode_tokens_batch: null argument"); return CZ_ERR_ARG; }
     HIPCHK(hipSetDevice(s->device));
     if (n_streams == 0) return CZ_OK;
@@ -879,6 +891,7 @@ extern "C" cz_status cz_decode_tokens(cz_session* s, const uint8_t* payload, siz
 
 // a second, independent session on the SAME device tensors (the reference loads the model a second time for that, src/main.rs:1943-1956)
 extern "C" cz_status cz_session_fork(cz_session* parent, cz_session** out) {
+    if (cz_dead(parent)) return CZ_ERR_STATE;
     if (!parent || !out) { cz_set_error("cz_session_fork: null argument"); return CZ_ERR_ARG; }
     *out = nullptr;
     if (parent->is_lane) { cz_set_error("cz_session_fork: fork the original session, not a fork"); return CZ_ERR_ARG; }
@@ -886,12 +899,13 @@ extern "C" cz_status cz_session_fork(cz_session* parent, cz_session** out) {
     cz_session* c = nullptr;
     CZCHK(make_lane(parent, &c));
     c->max_lanes = parent->max_lanes;                       // a fork may run its own lanes
-    c->fork_of = parent; parent->n_forks += 1;
+    c->fork_of = parent; parent->forks.push_back(c);
     *out = c;
     return CZ_OK;
 }
 extern "C" cz_status cz_xe_bits_batch(cz_session* s, size_t n_spans, const uint32_t* const* history, const size_t* n_history, const uint32_t* const* hint,
                                       const size_t* n_hint, const uint32_t* const* targets, const size_t* n_targets, double* bits_out) {
+    if (cz_dead(s)) return CZ_ERR_STATE;
     if (!s || !targets || !n_targets || !bits_out || (n_history && !history) || (n_hint && !hint)) { cz_set_error("cz_xe_bits_batch: null argument"); return CZ_ERR_ARG; }
     if (s->backend != CZ_BACKEND_SMOLLM) { cz_set_error("cz_xe_bits: only the smollm backend is supported (cross_entropy_bits_over_span_rwkv is not built)"); return CZ_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(s->device));

@@ -67,7 +67,8 @@ cz_status cz_session_open(const cz_model_desc* desc, int device_ordinal, cz_sess
 void cz_session_close(cz_session* s);
 /* A second, independent session on the SAME device weights (own stream, KV cache / recurrent state, buffers).  The reference gets a
  * second session by loading the model again (agent path, src/main.rs:1943-1956); a fork costs no weight memory and lets another
- * host thread compress while this one decompresses.  Close every fork before its parent. */
+ * host thread compress while this one decompresses.  Close every fork before its parent: a fork that outlives it fails every call
+ * (CZ_ERR_STATE) and can only be closed. */
 cz_status cz_session_fork(cz_session* parent, cz_session** out);
 
 /* trait LanguageModelSession (src/models.rs:28-33), 1:1 */

@@ -145,6 +145,14 @@ def test_session_fork_shares_weights(cz, czo, tiny_pair):
     with pytest.raises(cz.CandlezipError):
         f.fork()
     f.close()
+    # a fork that outlives its parent is a husk: every call fails loudly, closing it is still safe
+    p2 = cz.Session("smollm", cz.tiny_llama_config(), seed=11, embed_std=0.05, max_streams=2)
+    f2 = p2.fork()
+    p2.close()
+    with pytest.raises(cz.CandlezipError) as e:
+        f2.encode_tokens(a)
+    assert "parent" in str(e.value)
+    f2.close()
 
 
 def test_context_1024_and_small_intervals(cz, czo, tiny_pair):
