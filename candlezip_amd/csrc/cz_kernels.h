@@ -23,6 +23,8 @@ struct cz_rope_desc {
     int pad_;
 };
 
+hipError_t cz_launch_gu_interleave(hipStream_t st, const uint16_t* W, uint16_t* Wi, int f, int K);
+hipError_t cz_launch_gemm_swiglu(hipStream_t st, const float* A, int lda, const uint16_t* Wi, float* H, int ldh, int M, int f, int K);
 hipError_t cz_launch_gemm(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R, int ldr,
                           int M, int N, int K, int force_big);
 hipError_t cz_launch_embed(hipStream_t st, const uint32_t* tok, const uint16_t* E, float* X, int M, int d);

@@ -24,7 +24,8 @@ struct LlamaModel {
     uint16_t* blob = nullptr;          // one allocation: E | per-layer tensors | lnf   (bf16)
     uint16_t* blob_dec = nullptr;      // the same tensors with K in kq order (decode path); same offsets as blob
     uint16_t* E = nullptr;             // [vocab][d]  (tied lm_head)
-    struct Layer { uint16_t *ln1, *wqkv, *wo, *ln2, *wgu, *wd; };
+    struct Layer { uint16_t *ln1, *wqkv, *wo, *ln2, *wgu, *wd, *wgu_i; };   // wgu_i: gate|up rows interleaved by 32 for the fused SwiGLU epilogue (big-M path), or null
+    uint16_t* blob_gu = nullptr;       // storage of the wgu_i copies
     std::vector<Layer> L;
     uint16_t* lnf = nullptr;
     float *rope_cos = nullptr, *rope_sin = nullptr;   // [max_pos][32]

@@ -26,7 +26,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     return base + (bid >> 3);
 }
 
-template <int BM, int BN, int WM, int WN>
+// EPI = 1 (gate|up projection of the MLP): W holds the gate and up rows interleaved in groups of 32 (cz_launch_gu_interleave), so the two
+// 32-column MFMA tiles of a wave are the gate and the up values of the SAME 32 hidden columns and the epilogue writes
+// silu(gate) * up straight into H [M][N/2] — the 2 x f wide intermediate never exists in HBM.
+template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restrict__ A, int lda,
                                                          const uint16_t* __restrict__ W, float* __restrict__ C, int ldc,
                                                          const float* __restrict__ R, int ldr, int M, int N, int K,
@@ -128,6 +131,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restr
         if (kt + 1 < nk) { store_tile(); __syncthreads(); }
     }
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (EPI == 1) {
+        static_assert(EPI == 0 || TN == 2, "the SwiGLU epilogue pairs the two column tiles of a wave");
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int hcol = (bn * BN + wn * TN * 32) / 2 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bm * BM + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < M) C[(size_t)row * ldc + hcol] = cz_siluf(tot[i][0][r]) * tot[i][TN - 1][r];      // silu(gate) * up (llama.rs MLP)
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -209,12 +225,12 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const float* __restric
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int EPI = 0>
 static hipError_t launch_big(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R,
                              int ldr, int M, int N, int K) {
     static bool attr_set = false;
     const size_t smem = (size_t)(BM + BN) * LDK * sizeof(float);
-    auto kern = gemm_bf16w_kernel<BM, BN, WM, WN>;
+    auto kern = gemm_bf16w_kernel<BM, BN, WM, WN, EPI>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
@@ -223,6 +239,26 @@ static hipError_t launch_big(hipStream_t st, const float* A, int lda, const uint
     const int nbx = N / BN, nby = (M + BM - 1) / BM, nblocks = nbx * nby;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, st, A, lda, W, C, ldc, R, ldr, M, N, K, nbx, nblocks);
     return hipGetLastError();
+}
+
+// Wi[(c / 32) * 64 + (c % 32)] = gate row c, Wi[(c / 32) * 64 + 32 + (c % 32)] = up row c     (W = [gate rows (f) | up rows (f)], each K wide)
+__global__ void gu_interleave_kernel(const uint16_t* __restrict__ W, uint16_t* __restrict__ Wi, int f, int K) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)2 * f * K; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / K; const int k = (int)(i % K);
+        const int up = r >= (size_t)f, c = (int)(up ? r - f : r);
+        Wi[((size_t)(c / 32) * 64 + (up ? 32 : 0) + (c % 32)) * K + k] = W[i];
+    }
+}
+hipError_t cz_launch_gu_interleave(hipStream_t st, const uint16_t* W, uint16_t* Wi, int f, int K) {
+    if (f % 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gu_interleave_kernel, dim3(1024), dim3(256), 0, st, W, Wi, f, K);
+    return hipGetLastError();
+}
+// H[M][f] = silu(A . Wgate^T) * (A . Wup^T) with Wi from cz_launch_gu_interleave (big-M path only)
+hipError_t cz_launch_gemm_swiglu(hipStream_t st, const float* A, int lda, const uint16_t* Wi, float* H, int ldh, int M, int f, int K) {
+    if (M <= 0) return hipSuccess;
+    if (K % 64 != 0 || (2 * f) % 128 != 0) return hipErrorInvalidValue;
+    return launch_big<128, 128, 2, 2, 1>(st, A, lda, Wi, H, ldh, nullptr, 0, M, 2 * f, K);
 }
 
 hipError_t cz_launch_gemm(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R, int ldr,

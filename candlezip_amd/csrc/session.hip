@@ -242,6 +242,15 @@ static cz_status build_llama(cz_session* s, const cz_model_desc* desc) {
         HIPCHK(cz_launch_dec_pack(s->stream, y.wgu, dec(y.wgu), 2 * f, (int)d));
         HIPCHK(cz_launch_dec_pack(s->stream, y.wd, dec(y.wd), d, (int)f));
     }
+    // big-M path: gate|up rows interleaved so that the GEMM epilogue can apply SwiGLU (kernels_gemm.hip)
+    for (size_t l = 0; l < L; ++l) m.L[l].wgu_i = nullptr;
+    if ((2 * f) % 128 == 0 && f % 32 == 0) {
+        HIPCHK(hipMalloc((void**)&m.blob_gu, L * 2 * f * d * 2));
+        for (size_t l = 0; l < L; ++l) {
+            m.L[l].wgu_i = m.blob_gu + l * 2 * f * d;
+            HIPCHK(cz_launch_gu_interleave(s->stream, m.L[l].wgu, m.L[l].wgu_i, (int)f, (int)d));
+        }
+    }
     HIPCHK(hipStreamSynchronize(s->stream));
     return CZ_OK;
 }
@@ -253,10 +262,11 @@ static cz_status llama_body(cz_session* s, int M, const cz_seq_desc* seqd, const
     const LlamaModel& m = s->llama; const cz_llama_config& c = m.cfg;
     const int d = c.d_model, kvd = c.n_kv_heads * 64, f = c.d_ffn, nq = d + 2 * kvd;
     CZCHK(s->x.ensure((size_t)M * d * 4)); CZCHK(s->xn.ensure((size_t)M * d * 4));
-    CZCHK(s->qkv.ensure((size_t)M * nq * 4)); CZCHK(s->gu.ensure((size_t)M * 2 * f * 4)); CZCHK(s->h.ensure((size_t)M * f * 4));
+    const int big = s->force_big_gemm;
+    const bool fused_gu = m.L[0].wgu_i && (M > 64 || big);        // SwiGLU in the gate|up GEMM epilogue: the 2f-wide intermediate is never allocated
+    CZCHK(s->qkv.ensure((size_t)M * nq * 4)); if (!fused_gu) CZCHK(s->gu.ensure((size_t)M * 2 * f * 4)); CZCHK(s->h.ensure((size_t)M * f * 4));
     float *x = (float*)s->x.p, *xn = (float*)s->xn.p, *qkv = (float*)s->qkv.p, *gu = (float*)s->gu.p, *h = (float*)s->h.p;
     hipStream_t st = s->stream;
-    const int big = s->force_big_gemm;
     auto gemm = [&](const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R, int N, int K) -> hipError_t {
         s->prof_begin(M <= 64 && !big ? PK_GEMM_SKINNY : (N % 128 ? PK_GEMM_N64 : PK_GEMM));      // 128x64 tiles when N % 128 != 0 (kernels_gemm.hip)
         hipError_t e = cz_launch_gemm(st, A, lda, W, C, ldc, R, ldc, M, N, K, big);
@@ -278,8 +288,14 @@ static cz_status llama_body(cz_session* s, int M, const cz_seq_desc* seqd, const
         s->prof_end(4.0 * 64 * c.n_heads * (double)M * max_nk * 0.5, 0);
         HIPCHK(gemm(xn, d, y.wo, x, d, x, d, d));                           // x = attn_out . Wo^T + x
         s->prof_begin(PK_RMSNORM); HIPCHK(cz_launch_rmsnorm(st, x, d, y.ln2, xn, d, M, d, c.rms_eps, nullptr)); s->prof_end(0, (double)M * d * 8);
-        HIPCHK(gemm(xn, d, y.wgu, gu, 2 * f, nullptr, 2 * f, d));
-        s->prof_begin(PK_SWIGLU); HIPCHK(cz_launch_swiglu(st, gu, h, M, f)); s->prof_end(0, (double)M * f * 12);
+        if (fused_gu) {                                     // silu(gate) * up in the GEMM epilogue
+            s->prof_begin(PK_GEMM);
+            HIPCHK(cz_launch_gemm_swiglu(st, xn, d, y.wgu_i, h, f, M, f, d));
+            s->prof_end(4.0 * M * (double)f * d, (double)f * d * 4 + (double)M * (f + d) * 4);
+        } else {
+            HIPCHK(gemm(xn, d, y.wgu, gu, 2 * f, nullptr, 2 * f, d));
+            s->prof_begin(PK_SWIGLU); HIPCHK(cz_launch_swiglu(st, gu, h, M, f)); s->prof_end(0, (double)M * f * 12);
+        }
         HIPCHK(gemm(h, f, y.wd, x, d, x, d, f));                            // x = mlp_out + x
     }
     return CZ_OK;
@@ -400,7 +416,8 @@ static cz_status reserve_rows(cz_session* s, size_t M, size_t nlog) {
     const cz_llama_config& c = s->llama.cfg;
     const size_t d = c.d_model, kvd = (size_t)c.n_kv_heads * 64, f = c.d_ffn, nq = d + 2 * kvd;
     CZCHK(s->x.ensure(M * d * 4)); CZCHK(s->xn.ensure(M * d * 4)); CZCHK(s->qkv.ensure(M * nq * 4));
-    CZCHK(s->gu.ensure(M * 2 * f * 4)); CZCHK(s->h.ensure(M * f * 4)); CZCHK(s->xl.ensure(nlog * d * 4));
+    if (!(s->llama.L[0].wgu_i && (M > 64 || s->force_big_gemm))) CZCHK(s->gu.ensure(M * 2 * f * 4));
+    CZCHK(s->h.ensure(M * f * 4)); CZCHK(s->xl.ensure(nlog * d * 4));
     CZCHK(s->seqd.ensure(nlog * sizeof(cz_seq_desc))); CZCHK(s->roped.ensure(nlog * sizeof(cz_rope_desc))); CZCHK(s->rowidx.ensure(nlog * 4));
     return CZ_OK;
 }
@@ -749,13 +766,13 @@ extern "C" void cz_session_close(cz_session* s) {
     if (s->fork_of) { auto& v = s->fork_of->forks; v.erase(std::remove(v.begin(), v.end(), s), v.end()); }
     for (cz_session* f : s->forks) {                                // forks outlive their parent only as husks: no weights, every call fails
         f->fork_of = nullptr; f->orphan = true;
-        f->llama.blob = f->llama.blob_dec = nullptr; f->llama.rope_cos = f->llama.rope_sin = nullptr;
+        f->llama.blob = f->llama.blob_dec = f->llama.blob_gu = nullptr; f->llama.rope_cos = f->llama.rope_sin = nullptr;
     }
     s->forks.clear();
     hipSetDevice(s->device);
     for (cz_session* l : s->lanes) cz_session_close(l);
     s->lanes.clear();
-    if (s->is_lane) { s->llama.blob = s->llama.blob_dec = nullptr; s->llama.rope_cos = s->llama.rope_sin = nullptr; }   // the weights belong to the parent
+    if (s->is_lane) { s->llama.blob = s->llama.blob_dec = s->llama.blob_gu = nullptr; s->llama.rope_cos = s->llama.rope_sin = nullptr; }   // the weights belong to the parent
     if (s->stream) hipStreamSynchronize(s->stream);
     destroy_step_graph(s);
     s->prof_drain();
@@ -763,7 +780,7 @@ extern "C" void cz_session_close(cz_session* s) {
     DevBuf* bufs[] = {&s->tok, &s->x, &s->xn, &s->qkv, &s->gu, &s->h, &s->seqd, &s->roped, &s->rowidx, &s->sym, &s->clo, &s->chi, &s->xl,
                       &s->logits, &s->payload, &s->outids, &s->decst};
     for (auto b : bufs) b->release();
-    void* ptrs[] = {s->cdf_scratch, s->fallback_dev, s->llama.blob_dec, s->llama.blob, s->llama.rope_cos, s->llama.rope_sin, s->kvcache, s->pos_dev, s->step_seqd, s->step_roped, s->step_rows,
+    void* ptrs[] = {s->cdf_scratch, s->fallback_dev, s->llama.blob_gu, s->llama.blob_dec, s->llama.blob, s->llama.rope_cos, s->llama.rope_sin, s->kvcache, s->pos_dev, s->step_seqd, s->step_roped, s->step_rows,
                     s->step_logits, s->step_sym};
     for (auto p : ptrs) if (p) { hipError_t e = hipFree(p); (void)e; }
     cz_rwkv7_destroy(s);
