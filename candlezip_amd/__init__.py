@@ -12,6 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CANDLEZIP_AMD_LIB") or os.path.join(_HERE, "lib", "libcandlezip_hip.so")   # override: tuning builds only
 AC_CDF_TOTAL = 1 << 30
+FLAG_PRODUCER_HIP = 1 << 15     # include/candlezip.h CZ_FLAG_PRODUCER_HIP
 
 BACKEND_SMOLLM, BACKEND_RWKV7 = 0, 1
 _STATUS = {0: "CZ_OK", 1: "CZ_ERR_ARG", 2: "CZ_ERR_IO", 3: "CZ_ERR_HIP", 4: "CZ_ERR_STATE", 5: "CZ_ERR_UNSUPPORTED", 6: "CZ_ERR_FORMAT"}
@@ -69,7 +70,8 @@ def tiny_rwkv7_config(vocab=512, hidden=128, n_layers=2, d_ffn=512):
 
 EXPORTS = [  # every symbol include/candlezip.h declares
     "cz_session_open", "cz_session_close", "cz_session_fork", "cz_vocab_size", "cz_max_context_length", "cz_index_pos", "cz_step_logits",
-    "cz_reprime_logits", "cz_encode_tokens", "cz_encode_tokens_batch", "cz_decode_tokens", "cz_decode_tokens_batch",
+    "cz_reprime_logits", "cz_encode_tokens", "cz_encode_tokens_batch", "cz_encode_tokens_range_batch", "cz_decode_tokens", "cz_decode_tokens_batch",
+    "cz_decode_begin_batch", "cz_decode_advance", "cz_decode_fetch_batch", "cz_decode_end",
     "cz_ac_encode_pairs", "cz_free", "cz_write_header_v2", "cz_read_header_v2", "cz_flags_pack", "cz_skip_gate_section",
     "cz_blake3_bytes_bin16", "cz_blake3_file_bin16", "cz_blake3_files_bin16", "cz_rwkv_tokenizer_open",
     "cz_rwkv_tokenizer_close", "cz_rwkv_plan_symbols", "cz_rwkv_detok", "cz_bpe_tokenizer_open", "cz_bpe_tokenizer_close",
@@ -96,6 +98,10 @@ def lib():
         "cz_step_logits": (C.c_int, [vp, u32, vp]), "cz_reprime_logits": (C.c_int, [vp, vp, sz, vp]),
         "cz_encode_tokens": (C.c_int, [vp, vp, sz, u32, u32, vp, vp]),
         "cz_encode_tokens_batch": (C.c_int, [vp, sz, vp, vp, u32, u32, vp, vp]),
+        "cz_encode_tokens_range_batch": (C.c_int, [vp, sz, vp, vp, u32, u32, vp, vp, vp, vp]),
+        "cz_decode_begin_batch": (C.c_int, [vp, sz, vp, vp, vp, u32, u32, u32]),
+        "cz_decode_advance": (C.c_int, [vp, sz, C.POINTER(sz), C.POINTER(sz)]),
+        "cz_decode_fetch_batch": (C.c_int, [vp, sz, vp]), "cz_decode_end": (C.c_int, [vp]),
         "cz_decode_tokens": (C.c_int, [vp, vp, sz, sz, u32, u32, u32, vp]),
         "cz_decode_tokens_batch": (C.c_int, [vp, sz, vp, vp, vp, u32, u32, u32, vp]),
         "cz_ac_encode_pairs": (C.c_int, [vp, vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(u64)]),
@@ -112,6 +118,9 @@ def lib():
         "cz_bpe_tokenizer_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]), "cz_bpe_tokenizer_close": (None, [vp]), "cz_bpe_vocab_size": (sz, [vp]),
         "cz_bpe_encode": (C.c_int, [vp, vp, sz, C.POINTER(vp), C.POINTER(sz)]),
         "cz_bpe_decode": (C.c_int, [vp, vp, sz, C.c_int, C.POINTER(vp), C.POINTER(sz)]),
+        "cz_rwkv_tokenizer_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]), "cz_rwkv_tokenizer_close": (None, [vp]),
+        "cz_rwkv_plan_symbols": (C.c_int, [vp, vp, sz, u32, vp, sz, C.POINTER(sz)]),
+        "cz_rwkv_detok": (C.c_int, [vp, vp, sz, u32, C.POINTER(vp), C.POINTER(sz)]),
         "cz_profile_enable": (C.c_int, [vp, C.c_int]), "cz_profile_read": (C.c_int, [vp, vp, sz, C.POINTER(sz)]),
         "cz_synchronize": (C.c_int, [vp]),
         "cz_debug_set": (C.c_int, [vp, C.c_char_p, C.c_long]),
@@ -224,6 +233,39 @@ class Session:
 
     def encode_tokens(self, ids, context=512, reprime_interval=512):
         return self.encode_tokens_batch([ids], context, reprime_interval)[0]
+
+    def encode_tokens_range_batch(self, ids_list, ranges, context=512, reprime_interval=512):
+        """pairs of the coded tokens i in [b, e) of every stream (ranges = [(b, e), ...]); index 0 of the result is token b"""
+        ids_list = [np.ascontiguousarray(a, np.uint32) for a in ids_list]
+        n = np.array([a.size for a in ids_list], np.uint64)
+        ib = np.array([r[0] for r in ranges], np.uint64); ie = np.array([r[1] for r in ranges], np.uint64)
+        los = [np.zeros(max(int(e) - int(b), 1), np.uint32) for b, e in ranges]
+        his = [np.zeros(max(int(e) - int(b), 1), np.uint32) for b, e in ranges]
+        _check(lib().cz_encode_tokens_range_batch(self.h, len(ids_list), _ptr_array(ids_list), _p(n), context, reprime_interval, _p(ib), _p(ie),
+                                                  _ptr_array(los), _ptr_array(his)))
+        return [(lo[:int(e) - int(b)], hi[:int(e) - int(b)]) for (b, e), lo, hi in zip(ranges, los, his)]
+
+    # ---- the decode loop in slices (cz_decode_begin_batch / advance / fetch / end)
+    def decode_begin_batch(self, payloads, token_counts, context_window=512, reprime_interval=512, bos=0):
+        bufs = [np.frombuffer(bytes(p), np.uint8).copy() if len(p) else np.zeros(1, np.uint8) for p in payloads]
+        lens = np.array([len(p) for p in payloads], np.uint64)
+        tcs = np.array(token_counts, np.uint64)
+        self._run_tcs = [int(t) for t in token_counts]
+        _check(lib().cz_decode_begin_batch(self.h, len(payloads), _ptr_array(bufs), _p(lens), _p(tcs), context_window, reprime_interval, bos))
+
+    def decode_advance(self, n_tokens):
+        """decode up to n_tokens more tokens per stream; returns (position, remaining) of the longest stream"""
+        pos, rem = C.c_size_t(), C.c_size_t()
+        _check(lib().cz_decode_advance(self.h, int(n_tokens), C.byref(pos), C.byref(rem)))
+        return pos.value, rem.value
+
+    def decode_fetch_batch(self):
+        outs = [np.zeros(t + 1, np.uint32) for t in self._run_tcs]
+        _check(lib().cz_decode_fetch_batch(self.h, len(outs), _ptr_array(outs)))
+        return outs
+
+    def decode_end(self):
+        _check(lib().cz_decode_end(self.h))
 
     def decode_tokens_batch(self, payloads, token_counts, context_window=512, reprime_interval=512, bos=0):
         bufs = [np.frombuffer(bytes(p), np.uint8).copy() if len(p) else np.zeros(1, np.uint8) for p in payloads]
@@ -347,6 +389,38 @@ class BpeTokenizer:
         a = np.ascontiguousarray(ids, np.uint32)
         out, n = C.c_void_p(), C.c_size_t()
         _check(lib().cz_bpe_decode(self.h, a.ctypes.data if a.size else None, a.size, 1 if skip_special_tokens else 0, C.byref(out), C.byref(n)))
+        data = C.string_at(out, n.value) if n.value else b""
+        lib().cz_free(out)
+        return data
+
+
+class WorldTokenizer:
+    """RWKV "World" tokenizer (candle_rwkv7/src/models/rwkv7.rs:546-610) + plan_rwkv_symbols / rwkv_detok_with_literals
+    (src/main.rs:833-895), in-process through the C ABI (cz_rwkv_*)"""
+
+    def __init__(self, vocab_json_path):
+        h = C.c_void_p()
+        _check(lib().cz_rwkv_tokenizer_open(os.fsencode(vocab_json_path), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cz_rwkv_tokenizer_close(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def plan_symbols(self, data: bytes, vocab: int, ids_cap=None):
+        """symbols of `data`: token ids, or vocab + byte literals (uncovered tail / complete fallback)"""
+        buf = np.frombuffer(data, np.uint8) if len(data) else np.zeros(1, np.uint8)
+        cap = len(data) if ids_cap is None else ids_cap
+        out = np.zeros(max(cap, 1), np.uint32); n = C.c_size_t()
+        _check(lib().cz_rwkv_plan_symbols(self.h, buf.ctypes.data, len(data), vocab, out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def detok(self, ids, vocab: int) -> bytes:
+        a = np.ascontiguousarray(ids, np.uint32); out = C.c_void_p(); n = C.c_size_t()
+        _check(lib().cz_rwkv_detok(self.h, a.ctypes.data if a.size else None, a.size, vocab, C.byref(out), C.byref(n)))
         data = C.string_at(out, n.value) if n.value else b""
         lib().cz_free(out)
         return data

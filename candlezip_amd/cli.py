@@ -155,9 +155,7 @@ class _Model:
             self.vocab = self.sess.vocab_size()
             self.rwkv_tok = None
             if os.path.exists(args.rwkv_tokenizer):
-                h = C.c_void_p()
-                cz._check(cz.lib().cz_rwkv_tokenizer_open(args.rwkv_tokenizer.encode(), C.byref(h)))
-                self.rwkv_tok = h
+                self.rwkv_tok = cz.WorldTokenizer(args.rwkv_tokenizer)             # Tokenizer::new (rwkv7.rs:553), :1823
                 self.tok_hash = _hash_file(args.rwkv_tokenizer)
             else:
                 self.tok_hash = bytes(16)
@@ -173,12 +171,7 @@ class _Model:
             return np.asarray(self.tok.encode(data), np.uint32)
         if self.rwkv_tok is None:                                                      # complete fallback: literals (:863-868)
             return (np.frombuffer(data, np.uint8).astype(np.uint32) + self.vocab)
-        L = cz.lib()
-        L.cz_rwkv_plan_symbols.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.POINTER(C.c_size_t)]
-        buf = np.frombuffer(data, np.uint8) if data else np.zeros(1, np.uint8)
-        out = np.zeros(max(len(data), 1), np.uint32); n = C.c_size_t()
-        cz._check(L.cz_rwkv_plan_symbols(self.rwkv_tok, buf.ctypes.data, len(data), self.vocab, out.ctypes.data, C.byref(n)))
-        return out[: n.value].copy()
+        return self.rwkv_tok.plan_symbols(data, self.vocab)
 
     def detokenize(self, ids, args):
         if self.backend == "smollm":
@@ -187,21 +180,64 @@ class _Model:
             return self.tok.decode(ids, True)                                          # decode(ids, skip_special_tokens = true), :2654
         if self.rwkv_tok is None:
             return bytes(int(i) - self.vocab for i in ids if int(i) >= self.vocab)
-        L = cz.lib()
-        L.cz_rwkv_detok.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
-        a = np.ascontiguousarray(ids, np.uint32); out = C.c_void_p(); n = C.c_size_t()
-        cz._check(L.cz_rwkv_detok(self.rwkv_tok, a.ctypes.data, a.size, self.vocab, C.byref(out), C.byref(n)))
-        data = C.string_at(out, n.value) if n.value else b""
-        L.cz_free(out)
-        return data
+        return self.rwkv_tok.detok(ids, self.vocab)
+
+
+def _check_window(args):
+    """the reference's encoder keeps min(context, 511) tokens at a re-prime, its decoder min(context - 1, 511) (src/main.rs:1935 vs :2506):
+    for context < 512 the two sides disagree and the archive does not decode — reproduced literally, so say it loudly"""
+    if args.backend.lower() != "smollm":
+        return
+    if args.context <= 0:
+        sys.exit("error: --context must be > 0 (the reference fails with 'reprime called with empty history')")
+    if args.reprime_interval <= 0:
+        sys.exit("error: --reprime-interval must be > 0")
+    if args.context < 512:
+        print(f"warning: --context {args.context} < 512: encoder and decoder disagree on the re-prime window (min({args.context}, 511) vs "
+              f"min({args.context} - 1, 511), src/main.rs:1935 / :2506); like the reference's, an archive longer than one re-prime interval "
+              "will NOT decode", file=sys.stderr)
+
+
+def _dist(args):
+    """one process per GPU (torchrun): returns (torch.distributed or None, rank).  RCCL ("nccl") on a multi-GPU node; CZ_DIST_BACKEND=gloo
+    rehearses the same path on one GPU / in CPU tests.  Nothing in the token loop crosses ranks."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None, 0
+    import torch
+    import torch.distributed as dist
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("CZ_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            args.device = local
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist, rank
 
 
 def compress(args, inp, outp, model=None):
     t0 = time.perf_counter()
+    _check_window(args)
+    dist, rank = _dist(args)
     m = model or _Model(args)
     data = open(inp, "rb").read()
     ids = np.concatenate([[m.bos], m.tokenize(data, args)]).astype(np.uint32)          # :1850-1866
-    lo, hi = m.sess.encode_tokens(ids, args.context, args.reprime_interval)
+    if dist is not None and m.backend == "smollm":
+        # ONE file over the node's GPUs: every rank evaluates a block of whole re-prime segments, rank 0 gathers the (c_lo, c_hi) pairs,
+        # runs the serial coder and writes the single container (src/main.rs:2358-2376)
+        from candlezip_amd.parallel import encode_sharded
+        lo, hi = encode_sharded(lambda b, e: m.sess.encode_tokens_range_batch([ids], [(b, e)], args.context, args.reprime_interval)[0],
+                                ids.size - 1, args.reprime_interval, dist)
+        if rank != 0:
+            return m
+    elif dist is not None and rank != 0:
+        return m                                                                       # RWKV7 has no re-prime: one stream does not shard
+    else:
+        lo, hi = m.sess.encode_tokens(ids, args.context, args.reprime_interval)
     m.trace = {"encode_ids": ids[1:].copy(), "c_lo": lo, "c_hi": hi}                   # watchdog-lite (watchdog.py)
     payload, zero_width = cz.ac_encode_pairs(lo, hi)
     if zero_width:
@@ -211,7 +247,7 @@ def compress(args, inp, outp, model=None):
     for dst, src in ((h.model_hash16, m.model_hash), (h.tokenizer_hash16, m.tok_hash), (h.orig_hash16, cz.blake3_16(data))):
         C.memmove(dst, src, 16)
     chunk = 2048 if m.backend == "rwkv7" else args.reprime_interval                    # agent_chunk (:1869), packed even when the agent is off
-    h.reserved_flags = cz.lib().cz_flags_pack(0, 0, 0, chunk)
+    h.reserved_flags = cz.lib().cz_flags_pack(0, 0, 0, chunk) | cz.FLAG_PRODUCER_HIP    # producer mark (include/candlezip.h)
     h.context_window, h.vocab_size, h.reprime_interval = args.context, m.vocab, args.reprime_interval
     blob = cz.write_header(h, m.repr) + payload                                        # :2362-2376
     open(outp, "wb").write(blob)
@@ -223,6 +259,9 @@ def compress(args, inp, outp, model=None):
 
 
 def decompress(args, inp, outp, model=None):
+    dist, rank = _dist(args)
+    if dist is not None and rank != 0:
+        return model                                                                   # one stream decodes sequentially: rank 0 only
     buf = open(inp, "rb").read()
     h, repr_, n = cz.read_header(buf)                                                  # :2411
     if h.reserved_flags & 1:
@@ -232,6 +271,12 @@ def decompress(args, inp, outp, model=None):
         cz._check(cz.lib().cz_skip_gate_section(a.ctypes.data, a.size, C.byref(used)))
         n += used.value
     m = model or _Model(args)
+    if not (h.reserved_flags & cz.FLAG_PRODUCER_HIP):
+        msg = ("this .canz does not carry the producer mark of this build (reserved_flags bit 15): it was written by another implementation "
+               "(e.g. the candle reference), whose logits arithmetic differs, so its payload would decode to garbage here")
+        if not args.force_mismatch:
+            sys.exit(f"producer mismatch: {msg}. Use --force-mismatch to override.")
+        print(f"warning: {msg}", file=sys.stderr)
     if not args.force_mismatch:                                                        # :2448-2459
         if m.model_hash != bytes(h.model_hash16):
             sys.exit("model hash mismatch. Use --force-mismatch to override.")
@@ -285,12 +330,22 @@ def self_test(args, inp):
 def main(argv=None):
     args = build_parser().parse_args(argv)
     _reject_agent(args)
+    rc = 0
     if args.command == "compress":
         compress(args, args.input, args.output)
     elif args.command == "decompress":
         decompress(args, args.input, args.output)
     else:
-        sys.exit(self_test(args, args.input))
+        dist, rank = _dist(args)
+        if dist is not None and rank != 0:                                             # ranks > 0 only help with the compress half
+            compress(args, args.input, os.devnull)
+        else:
+            rc = self_test(args, args.input)
+    dist, _ = _dist(args)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -386,10 +386,16 @@ extern "C" cz_status cz_rwkv_tokenizer_open(const char* path, cz_rwkv_tokenizer*
     cz_rwkv_tokenizer* t = new cz_rwkv_tokenizer();
     t->table.resize(65536); t->good.assign(65536, 0);
     uint32_t max_idx = 0;
+    for (auto& kv : root.obj) {                                                     // HashMap<String, u32>: the last duplicate key wins
+        if (kv.second.kind != JsonValue::Num) { delete t; cz_set_error("rwkv vocab json: value of \"%s\" is not a number", kv.first.c_str()); return CZ_ERR_IO; }
+        t->token2idx[kv.first] = (uint32_t)kv.second.num;
+    }
+    // idx2token from the final map (rwkv7.rs:557).  Two keys with one id: the reference keeps whichever its HashMap iteration meets
+    // last (unspecified); here the last one in file order, deterministically.
     for (auto& kv : root.obj) {
-        if (kv.second.kind != JsonValue::Num) continue;
-        uint32_t id = (uint32_t)kv.second.num;
-        t->token2idx[kv.first] = id; t->idx2token[id] = kv.first;
+        const uint32_t id = (uint32_t)kv.second.num;
+        if (t->token2idx[kv.first] != id) continue;
+        t->idx2token[id] = kv.first;
         if (id > max_idx) max_idx = id;
     }
     for (uint64_t idx = (uint64_t)max_idx + 1; idx-- > 0;) {                       // (0..1+max_idx).rev()
@@ -423,8 +429,8 @@ static bool rwkv_encode_bytes(const cz_rwkv_tokenizer* t, const uint8_t* b, size
     return true;
 }
 extern "C" cz_status cz_rwkv_plan_symbols(const cz_rwkv_tokenizer* t, const uint8_t* bytes, size_t n_bytes, uint32_t vocab,
-                                          uint32_t* ids_out, size_t* n_ids) {       // src/main.rs:833-870
-    if (!t || (!bytes && n_bytes) || !ids_out || !n_ids) { cz_set_error("cz_rwkv_plan_symbols: null argument"); return CZ_ERR_ARG; }
+                                          uint32_t* ids_out, size_t ids_cap, size_t* n_ids) {       // src/main.rs:833-870
+    if (!t || (!bytes && n_bytes) || (!ids_out && ids_cap) || !n_ids) { cz_set_error("cz_rwkv_plan_symbols: null argument"); return CZ_ERR_ARG; }
     std::vector<uint32_t> ids;
     if (rwkv_encode_bytes(t, bytes, n_bytes, &ids)) {
         size_t covered = 0;
@@ -434,8 +440,9 @@ extern "C" cz_status cz_rwkv_plan_symbols(const cz_rwkv_tokenizer* t, const uint
         ids.clear();
         for (size_t i = 0; i < n_bytes; ++i) ids.push_back(vocab + bytes[i]);      // complete fallback: literals
     }
-    memcpy(ids_out, ids.data(), ids.size() * 4);
     *n_ids = ids.size();
+    if (ids.size() > ids_cap) { cz_set_error("cz_rwkv_plan_symbols: %zu symbols do not fit ids_cap = %zu", ids.size(), ids_cap); return CZ_ERR_ARG; }
+    if (!ids.empty()) memcpy(ids_out, ids.data(), ids.size() * 4);
     return CZ_OK;
 }
 extern "C" cz_status cz_rwkv_detok(const cz_rwkv_tokenizer* t, const uint32_t* ids, size_t n, uint32_t vocab, uint8_t** out, size_t* out_len) {

@@ -40,6 +40,16 @@ static inline uint32_t cz_f32_bits_round_bf16(uint32_t u) {
 
 struct Rwkv7Model;   // rwkv7.hip
 
+// a lock-step decode in progress on one lane (cz_decode_begin_batch ... cz_decode_end): host-side cursor of the token loop; everything
+// else (KV cache / recurrent state, arithmetic-decoder states, decoded ids, position counters) is device-resident
+struct DecRun {
+    bool active = false, use_graph = false;
+    int B = 0;
+    std::vector<size_t> tcs;
+    size_t max_tc = 0, i = 0, index_pos = 0, ec = 0, ids_total = 0;
+    uint32_t R = 0, bos = 0;
+};
+
 struct cz_session {
     cz_backend backend = CZ_BACKEND_SMOLLM;
     int device = 0;
@@ -71,6 +81,8 @@ struct cz_session {
     cz_seq_desc* step_seqd = nullptr; cz_rope_desc* step_roped = nullptr; int* step_rows = nullptr;
     float* step_logits = nullptr; uint32_t* step_sym = nullptr;
     size_t index_pos = 0;              // SmolLmSession::index_pos (src/models.rs:65)
+    DecRun run;                        // this lane's group of a sliced decode
+    std::vector<size_t> run_off;       // parent only: group g of the sliced decode = streams [run_off[g], run_off[g+1]) on lane g
     // profiling
     bool prof_on = false, prof_cur = false; unsigned prof_mask = 0xFFFFFFFFu;
     ProfAcc acc[PK_COUNT];
@@ -88,5 +100,8 @@ cz_status cz_rwkv7_step_host(cz_session* s, uint32_t token, float* out_logits);
 cz_status cz_rwkv7_reprime_host(cz_session* s, const uint32_t* hist, size_t n, float* out_logits);
 cz_status cz_rwkv7_make_lane(const cz_session* parent, cz_session* child);
 cz_status cz_rwkv7_encode_group(cz_session* s, int B, const uint32_t* const* ids, const size_t* n, uint32_t* const* lo, uint32_t* const* hi);
+cz_status cz_rwkv7_decode_begin(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs, uint32_t bos);
+cz_status cz_rwkv7_decode_advance(cz_session* s, size_t n);
+cz_status cz_rwkv7_decode_fetch(cz_session* s, uint32_t* const* out_ids);
 cz_status cz_rwkv7_decode_group(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs, uint32_t bos,
                                 uint32_t* const* out_ids);

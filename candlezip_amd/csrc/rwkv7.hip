@@ -525,6 +525,20 @@ cz_status cz_rwkv7_make_lane(const cz_session* parent, cz_session* child) {
     return CZ_OK;
 }
 
+// decode_symbol(i) for every stream, then (optionally) the model step on the decoded symbols
+static cz_status rw_decode_iteration(cz_session* s, int B, unsigned long long i, const unsigned long long* step_dev, bool step_after) {
+    Rwkv7Model* m = s->rwkv; const cz_rwkv7_config& c = m->cfg;
+    cz_dec_state* dst = (cz_dec_state*)s->decst.p;
+    s->prof_begin(PK_DECODE);
+    HIPCHK(cz_launch_decode_symbol(s->stream, m->logits, c.vocab, dst, m->sym, B, c.vocab, 1, i, s->fallback_dev, step_dev, s->cdf_scratch));
+    s->prof_end(0, (double)B * c.vocab * 4);
+    if (step_after) {
+        hipLaunchKernelGGL(rw_mask_from_sym_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, dst, m->sym, (uint32_t)c.vocab, m->tok, m->mask, B, i, step_dev);
+        CZCHK(rw_step(s, B));
+    }
+    return CZ_OK;
+}
+
 // one lock-step group of B <= max_streams streams
 cz_status cz_rwkv7_encode_group(cz_session* s, int B, const uint32_t* const* ids, const size_t* n, uint32_t* const* lo, uint32_t* const* hi) {
     Rwkv7Model* m = s->rwkv; const cz_rwkv7_config& c = m->cfg;
@@ -584,10 +598,12 @@ cz_status cz_rwkv7_encode_group(cz_session* s, int B, const uint32_t* const* ids
     return CZ_OK;
 }
 
-cz_status cz_rwkv7_decode_group(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs, uint32_t bos,
-                                uint32_t* const* out_ids) {
+// the decode loop in slices (begin -> advance(n)* -> fetch), like the LLaMA one: recurrent state, decoder states and ids stay in HBM
+cz_status cz_rwkv7_decode_begin(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs, uint32_t bos) {
     Rwkv7Model* m = s->rwkv; const cz_rwkv7_config& c = m->cfg;
     const uint32_t V = (uint32_t)c.vocab;
+    DecRun& run = s->run;
+    run.active = false;
     if (bos >= V) { cz_set_error("bos id %u >= vocab", bos); return CZ_ERR_ARG; }
     CZCHK(rw_ensure_streams(s, B));
     CZCHK(rw_reset(s));
@@ -612,34 +628,48 @@ cz_status cz_rwkv7_decode_group(cz_session* s, int B, const uint8_t* const* payl
     hipLaunchKernelGGL(rw_fill_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, m->sym, m->mask, bos, B);
     CZCHK(rw_step(s, B));                                            // step(bos) (src/main.rs:2485 equivalent for rwkv)
     const bool use_graph = !s->no_graph && !s->prof_on && cz_cdf_par_supported(c.vocab, 1);
-    auto iteration = [&](unsigned long long i, const unsigned long long* step_dev, bool step_after) -> cz_status {
-        s->prof_begin(PK_DECODE);
-        HIPCHK(cz_launch_decode_symbol(s->stream, m->logits, c.vocab, dst, m->sym, B, c.vocab, 1, i, s->fallback_dev, step_dev, s->cdf_scratch));
-        s->prof_end(0, (double)B * c.vocab * 4);
-        if (step_after) {
-            hipLaunchKernelGGL(rw_mask_from_sym_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, dst, m->sym, V, m->tok, m->mask, B, i, step_dev);
-            CZCHK(rw_step(s, B));
-        }
-        return CZ_OK;
-    };
     if (use_graph) {
         if (!m->gdec.e || m->gdec.B != B || m->gdec.gen != s->devbuf_gen)
             CZCHK(rw_graph_build(s, m->gdec, B, [&]() -> cz_status {
-                CZCHK(iteration(0, m->step_dev, true));              // (the step after the last symbol is harmless: its logits are never read)
+                CZCHK(rw_decode_iteration(s, B, 0, m->step_dev, true));   // (the step after the last symbol is harmless: its logits are never read)
                 hipLaunchKernelGGL(rw_counter_kernel, dim3(1), dim3(1), 0, s->stream, m->step_dev, 1);
                 return CZ_OK;
             }));
         hipLaunchKernelGGL(rw_counter_kernel, dim3(1), dim3(1), 0, s->stream, m->step_dev, 0);
     }
-    for (size_t i = 0; i < max_tc; ++i) {
-        if (use_graph) HIPCHK(hipGraphLaunch(m->gdec.e, s->stream));
-        else CZCHK(iteration((unsigned long long)i, nullptr, i + 1 < max_tc));
-    }
-    std::vector<uint32_t> all(ids_total);
-    HIPCHK(hipMemcpyAsync(all.data(), s->outids.p, ids_total * 4, hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
-    io = 0;
-    for (int b = 0; b < B; ++b) { memcpy(out_ids[b], all.data() + io, (tcs[b] + 1) * 4); if (tcs[b] == 0) out_ids[b][0] = bos; io += tcs[b] + 1; }
-    s->index_pos = 0;
+    run.B = B; run.tcs.assign(tcs, tcs + B); run.max_tc = max_tc; run.i = 0; run.index_pos = 0; run.ec = 0; run.R = 0; run.bos = bos;
+    run.ids_total = ids_total; run.use_graph = use_graph; run.active = true;
     return CZ_OK;
+}
+cz_status cz_rwkv7_decode_advance(cz_session* s, size_t n) {
+    Rwkv7Model* m = s->rwkv;
+    DecRun& run = s->run;
+    if (!run.active) { cz_set_error("no decode in progress on this session (cz_decode_begin_batch first)"); return CZ_ERR_STATE; }
+    const size_t stop = run.max_tc - run.i < n ? run.max_tc : run.i + n;
+    for (size_t i = run.i; i < stop; ++i) {
+        if (run.use_graph) HIPCHK(hipGraphLaunch(m->gdec.e, s->stream));
+        else CZCHK(rw_decode_iteration(s, run.B, (unsigned long long)i, nullptr, i + 1 < run.max_tc));
+    }
+    run.i = stop;
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return CZ_OK;
+}
+cz_status cz_rwkv7_decode_fetch(cz_session* s, uint32_t* const* out_ids) {
+    DecRun& run = s->run;
+    if (!run.active) { cz_set_error("no decode in progress on this session (cz_decode_begin_batch first)"); return CZ_ERR_STATE; }
+    std::vector<uint32_t> all(run.ids_total);
+    HIPCHK(hipMemcpyAsync(all.data(), s->outids.p, run.ids_total * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    size_t io = 0;
+    for (int b = 0; b < run.B; ++b) { memcpy(out_ids[b], all.data() + io, (run.tcs[b] + 1) * 4); if (run.tcs[b] == 0) out_ids[b][0] = run.bos; io += run.tcs[b] + 1; }
+    return CZ_OK;
+}
+cz_status cz_rwkv7_decode_group(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs, uint32_t bos,
+                                uint32_t* const* out_ids) {
+    CZCHK(cz_rwkv7_decode_begin(s, B, payloads, lens, tcs, bos));
+    cz_status rc = cz_rwkv7_decode_advance(s, s->run.max_tc);
+    if (rc == CZ_OK) rc = cz_rwkv7_decode_fetch(s, out_ids);
+    s->run.active = false;
+    s->index_pos = 0;
+    return rc;
 }

@@ -478,15 +478,28 @@ static void plan_segments(int stream, size_t n_ids, uint32_t context, uint32_t R
 }
 
 // ------------------------------------------------------------------ encode
+// i_begin / i_end (optional, per stream): only the coded tokens i in [i_begin, i_end) are evaluated and out_lo/out_hi are indexed by
+// i - i_begin.  A re-prime segment depends on token ids alone, never on another segment's activations, so any range of any
+// stream can be computed on any GPU: this is what shards ONE file's encode over ranks.
 static cz_status encode_llama(cz_session* s, size_t n_streams, const uint32_t* const* ids, const size_t* n, uint32_t context,
-                              uint32_t R, uint32_t* const* out_lo, uint32_t* const* out_hi) {
+                              uint32_t R, const size_t* i_begin, const size_t* i_end, uint32_t* const* out_lo, uint32_t* const* out_hi) {
     const cz_llama_config& c = s->llama.cfg;
     if (R == 0) { cz_set_error("reprime_interval must be > 0"); return CZ_ERR_ARG; }       // the reference would panic on i % 0
+    if (context == 0) { cz_set_error("reprime called with empty history (context must be > 0)"); return CZ_ERR_ARG; }   // src/models.rs:108
     std::vector<Seg> segs;
     for (size_t st = 0; st < n_streams; ++st) {
         if (n[st] == 0) { cz_set_error("stream %zu is empty (ids must start with BOS)", st); return CZ_ERR_ARG; }
         for (size_t i = 0; i < n[st]; ++i) if (ids[st][i] >= (uint32_t)c.vocab) { cz_set_error("token id %u >= vocab %d", ids[st][i], c.vocab); return CZ_ERR_ARG; }
-        plan_segments((int)st, n[st], context, R, &segs);
+        const size_t rb = i_begin ? i_begin[st] : 0, re = i_end ? i_end[st] : n[st] - 1;
+        if (rb > re || re > n[st] - 1) { cz_set_error("stream %zu: token range [%zu, %zu) outside [0, %zu)", st, rb, re, n[st] - 1); return CZ_ERR_ARG; }
+        std::vector<Seg> all;
+        plan_segments((int)st, n[st], context, R, &all);
+        for (Seg sg : all) {                                     // clip to the range: rows after the last wanted logits row are not needed (causal)
+            if (sg.end_i <= rb || sg.start_i >= re) continue;
+            if (sg.start_i < rb) sg.start_i = rb;
+            if (sg.end_i > re) sg.end_i = re;
+            segs.push_back(sg);
+        }
     }
     for (auto& sg : segs) {
         size_t T = sg.end_i - sg.hist_start;
@@ -548,7 +561,10 @@ static cz_status encode_llama(cz_session* s, size_t n_streams, const uint32_t* c
         HIPCHK(hipMemcpyAsync(lo.data(), s->clo.p, Lr * 4, hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipMemcpyAsync(hi.data(), s->chi.p, Lr * 4, hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
-        for (size_t r = 0; r < Lr; ++r) { out_lo[dst[r].stream][dst[r].i] = lo[r]; out_hi[dst[r].stream][dst[r].i] = hi[r]; }
+        for (size_t r = 0; r < Lr; ++r) {
+            const size_t o = dst[r].i - (i_begin ? i_begin[dst[r].stream] : 0);
+            out_lo[dst[r].stream][o] = lo[r]; out_hi[dst[r].stream][o] = hi[r];
+        }
         si = sj;
     }
     return CZ_OK;
@@ -636,9 +652,13 @@ static cz_status xe_llama(cz_session* s, size_t n_spans, const uint32_t* const* 
 }
 
 // ------------------------------------------------------------------ decode (lock-step)
-static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs,
-                                    uint32_t context_window, uint32_t R, uint32_t bos, uint32_t* const* out_ids) {
+// One lock-step group lives on one lane (session): its KV cache, arithmetic-decoder states, decoded ids and position counters stay
+// in HBM between calls, so the loop of decode_file (src/main.rs:2528-2541, 2621-2628) can be run in slices: begin -> advance(n)* -> fetch.
+static cz_status decode_llama_begin(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs,
+                                    uint32_t context_window, uint32_t R, uint32_t bos) {
     const cz_llama_config& c = s->llama.cfg;
+    DecRun& run = s->run;
+    run.active = false;
     if (R == 0) { cz_set_error("reprime_interval must be > 0"); return CZ_ERR_ARG; }
     if (bos >= (uint32_t)c.vocab) { cz_set_error("bos id %u >= vocab", bos); return CZ_ERR_ARG; }
     CZCHK(ensure_streams(s, B));
@@ -669,7 +689,6 @@ static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* 
     hipLaunchKernelGGL(fill_u32_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, s->step_sym, bos, B);   // finished streams keep a valid id
     s->index_pos = 0;                                                                        // the single-stream step state is reset
     CZCHK(llama_step(s, B, 0));                                                              // step(bos) (:2485)
-    size_t index_pos = 1;
     size_t ec = context_window > 0 ? context_window - 1 : 0; if (ec > 511) ec = 511;         // :2506
     // graph replay unless per-kernel profiling of the decode families is requested or the graph path is disabled
     const unsigned dec_kinds = (1u << PK_DECODE) | (1u << PK_DEC_GEMM) | (1u << PK_DEC_GEMM_QKV) | (1u << PK_DEC_GEMM_GU) | (1u << PK_DEC_GEMM_HEAD) | (1u << PK_DEC_ATTN) | (1u << PK_DEC_NORM) | (1u << PK_EMBED);
@@ -680,21 +699,33 @@ static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* 
         if (s->graph_gen != s->devbuf_gen) CZCHK(build_step_graph(s, B));                     // the dry run itself grew a buffer: capture again
         CZCHK(llama_step(s, B, 0));                                                          // the dry run clobbered the BOS logits
     }
-    const unsigned long long* step_dev = reinterpret_cast<const unsigned long long*>(s->pos_dev + 2);
-    hipLaunchKernelGGL(set_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, (int)index_pos, 0ull);
-    for (size_t i = 0; i < max_tc; ++i) {
+    hipLaunchKernelGGL(set_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, 1, 0ull);
+    run.B = B; run.tcs.assign(tcs, tcs + B); run.max_tc = max_tc; run.i = 0; run.index_pos = 1; run.ec = ec; run.R = R; run.bos = bos;
+    run.ids_total = ids_total; run.use_graph = use_graph; run.active = true;
+    return CZ_OK;
+}
+// up to n more tokens of every stream of the group (streams shorter than the longest simply finish earlier)
+static cz_status decode_llama_advance(cz_session* s, size_t n) {
+    const cz_llama_config& c = s->llama.cfg;
+    DecRun& run = s->run;
+    if (!run.active) { cz_set_error("no decode in progress on this session (cz_decode_begin_batch first)"); return CZ_ERR_STATE; }
+    const int B = run.B; const size_t R = run.R, ec = run.ec;
+    cz_dec_state* dst = (cz_dec_state*)s->decst.p;
+    const size_t stop = run.max_tc - run.i < n ? run.max_tc : run.i + n;
+    for (size_t i = run.i; i < stop; ++i) {
+        size_t& index_pos = run.index_pos;
         if (index_pos >= ec && (i % R) == 0 && i > 0) {                                      // :2532
             const size_t end = i + 1, hl = end > ec ? ec : end;                              // out_tokens.len() == i + 1
-            if (hl == 0) { cz_set_error("reprime called with empty history"); return CZ_ERR_STATE; }
+            if (hl == 0) { cz_set_error("reprime called with empty history"); run.active = false; return CZ_ERR_STATE; }
             hipLaunchKernelGGL(gather_hist_kernel, dim3((unsigned)((B * hl + 255) / 256)), dim3(256), 0, s->stream, dst, (uint32_t*)s->tok.p, B, (int)hl,
                                (unsigned long long)end);
             CZCHK(llama_reprime(s, B, (int)hl));
-            if (use_graph && s->graph_gen != s->devbuf_gen) { cz_set_error("internal: a work buffer moved under the captured decode graph"); return CZ_ERR_STATE; }
+            if (run.use_graph && s->graph_gen != s->devbuf_gen) { cz_set_error("internal: a work buffer moved under the captured decode graph"); run.active = false; return CZ_ERR_STATE; }
             index_pos = hl;
             hipLaunchKernelGGL(set_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, (int)index_pos, (unsigned long long)i);
         }
-        if (index_pos >= (size_t)CZ_MAX_CTX || index_pos >= s->ctx_cap) { cz_set_error("position %zu exceeds the supported context (%d)", index_pos, CZ_MAX_CTX); return CZ_ERR_STATE; }
-        if (use_graph) {
+        if (index_pos >= (size_t)CZ_MAX_CTX || index_pos >= s->ctx_cap) { cz_set_error("position %zu exceeds the supported context (%d)", index_pos, CZ_MAX_CTX); run.active = false; return CZ_ERR_STATE; }
+        if (run.use_graph) {
             if (s->probe_launch && i < 64) HIPCHK(hipStreamSynchronize(s->stream));          // probe: cost of a launch into an empty queue
             timespec c0, c1; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c0);
             const auto t0 = std::chrono::steady_clock::now();
@@ -709,7 +740,7 @@ static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* 
             if (s->serial_cdf) HIPCHK(cz_launch_decode_symbol_serial(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, (unsigned long long)i, nullptr));
             else HIPCHK(cz_launch_decode_symbol(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, (unsigned long long)i, s->fallback_dev, nullptr, s->cdf_scratch));
             s->prof_end(0, (double)B * c.vocab * 4);
-            if (i + 1 < max_tc) {
+            if (i + 1 < run.max_tc) {
                 // the reference also steps after the last symbol (:2627); its logits are never used, so it is skipped here
                 HIPCHK(hipMemcpyAsync(s->tok.p, s->step_sym, (size_t)B * 4, hipMemcpyDeviceToDevice, s->stream));
                 CZCHK(llama_step(s, B, (int)index_pos));
@@ -717,13 +748,28 @@ static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* 
         }
         index_pos += 1;
     }
-    (void)step_dev;
-    std::vector<uint32_t> all(ids_total);
-    HIPCHK(hipMemcpyAsync(all.data(), s->outids.p, ids_total * 4, hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
-    io = 0;
-    for (int b = 0; b < B; ++b) { memcpy(out_ids[b], all.data() + io, (tcs[b] + 1) * 4); if (tcs[b] == 0) out_ids[b][0] = bos; io += tcs[b] + 1; }
+    run.i = stop;
+    HIPCHK(hipStreamSynchronize(s->stream));       // the slice is done when the call returns (and a faulting kernel is reported by this call)
     return CZ_OK;
+}
+// ids decoded so far (token_count + 1 per stream, BOS first; entries past the decoded position are unspecified)
+static cz_status decode_llama_fetch(cz_session* s, uint32_t* const* out_ids) {
+    DecRun& run = s->run;
+    if (!run.active) { cz_set_error("no decode in progress on this session (cz_decode_begin_batch first)"); return CZ_ERR_STATE; }
+    std::vector<uint32_t> all(run.ids_total);
+    HIPCHK(hipMemcpyAsync(all.data(), s->outids.p, run.ids_total * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    size_t io = 0;
+    for (int b = 0; b < run.B; ++b) { memcpy(out_ids[b], all.data() + io, (run.tcs[b] + 1) * 4); if (run.tcs[b] == 0) out_ids[b][0] = run.bos; io += run.tcs[b] + 1; }
+    return CZ_OK;
+}
+static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs,
+                                    uint32_t context_window, uint32_t R, uint32_t bos, uint32_t* const* out_ids) {
+    CZCHK(decode_llama_begin(s, B, payloads, lens, tcs, context_window, R, bos));
+    cz_status rc = decode_llama_advance(s, s->run.max_tc);
+    if (rc == CZ_OK) rc = decode_llama_fetch(s, out_ids);
+    s->run.active = false;
+    return rc;
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -842,6 +888,10 @@ static cz_status make_lane(cz_session* p, cz_session** out) {
     *out = c;
     return CZ_OK;
 }
+static void lane_inherit(const cz_session* s, cz_session* ls) {   // a lane runs with its parent's knobs
+    ls->kv_ctx_cap = s->kv_ctx_cap; ls->serial_cdf = s->serial_cdf; ls->decode_v1 = s->decode_v1; ls->no_graph = s->no_graph; ls->force_big_gemm = s->force_big_gemm;
+    ls->max_batch_rows = s->max_batch_rows; ls->logit_batch_rows = s->logit_batch_rows;
+}
 // run `n_streams` streams as groups of <= max_streams on up to max_lanes lanes; group(ls, off, count) processes streams [off, off + count)
 template <class GroupFn>
 static cz_status run_on_lanes(cz_session* s, size_t n_streams, GroupFn group) {
@@ -856,8 +906,7 @@ static cz_status run_on_lanes(cz_session* s, size_t n_streams, GroupFn group) {
     auto run = [&](size_t l) {
         cz_session* ls = l == 0 ? s : s->lanes[l - 1];
         if (hipSetDevice(s->device) != hipSuccess) { rc[l] = CZ_ERR_HIP; msg[l] = "hipSetDevice failed"; return; }
-        if (l) { ls->kv_ctx_cap = s->kv_ctx_cap; ls->serial_cdf = s->serial_cdf; ls->decode_v1 = s->decode_v1; ls->no_graph = s->no_graph; ls->force_big_gemm = s->force_big_gemm;
-                 ls->max_batch_rows = s->max_batch_rows; ls->logit_batch_rows = s->logit_batch_rows; }
+        if (l) lane_inherit(s, ls);
         for (size_t g = l; g < G && rc[l] == CZ_OK; g += L) {
             rc[l] = group(ls, off[g], off[g + 1] - off[g]);
             if (rc[l] != CZ_OK) msg[l] = cz_last_error();
@@ -882,7 +931,7 @@ extern "C" cz_status cz_encode_tokens_batch(cz_session* s, size_t n_streams, con
             return cz_rwkv7_encode_group(ls, (int)cnt, ids + o, n + o, out_c_lo + o, out_c_hi + o);
         });
     }
-    return encode_llama(s, n_streams, ids, n, context, reprime_interval, out_c_lo, out_c_hi);
+    return encode_llama(s, n_streams, ids, n, context, reprime_interval, nullptr, nullptr, out_c_lo, out_c_hi);
 }
 extern "C" cz_status cz_encode_tokens(cz_session* s, const uint32_t* ids, size_t n, uint32_t context, uint32_t reprime_interval,
                                       uint32_t* out_c_lo, uint32_t* out_c_hi) {
@@ -904,6 +953,92 @@ extern "C" cz_status cz_decode_tokens_batch(cz_session* s, size_t n_streams, con
 extern "C" cz_status cz_decode_tokens(cz_session* s, const uint8_t* payload, size_t len, size_t token_count, uint32_t context_window,
                                       uint32_t reprime_interval, uint32_t bos, uint32_t* out_ids) {
     return cz_decode_tokens_batch(s, 1, &payload, &len, &token_count, context_window, reprime_interval, bos, &out_ids);
+}
+
+// ---- the decode loop in slices.  Every lock-step group stays resident on a lane of its own between the calls, so the streams must fit
+// max_streams x max_lanes.  group(ls, g) runs on lane g's host thread.
+template <class GroupFn>
+static cz_status on_run_groups(cz_session* s, GroupFn group) {
+    const size_t G = s->run_off.size() > 1 ? s->run_off.size() - 1 : 0;
+    if (G == 0) { cz_set_error("no decode in progress on this session (cz_decode_begin_batch first)"); return CZ_ERR_STATE; }
+    std::vector<cz_status> rc(G, CZ_OK); std::vector<std::string> msg(G);
+    auto run = [&](size_t g) {
+        cz_session* ls = g == 0 ? s : s->lanes[g - 1];
+        if (hipSetDevice(s->device) != hipSuccess) { rc[g] = CZ_ERR_HIP; msg[g] = "hipSetDevice failed"; return; }
+        if (g) lane_inherit(s, ls);
+        rc[g] = group(ls, g);
+        if (rc[g] != CZ_OK) msg[g] = cz_last_error();
+    };
+    std::vector<std::thread> th;
+    for (size_t g = 1; g < G; ++g) th.emplace_back(run, g);
+    run(0);
+    for (auto& t : th) t.join();
+    for (size_t g = 0; g < G; ++g) if (rc[g] != CZ_OK) { cz_set_error("%s", msg[g].c_str()); return rc[g]; }
+    return CZ_OK;
+}
+extern "C" cz_status cz_decode_begin_batch(cz_session* s, size_t n_streams, const uint8_t* const* payloads, const size_t* lens, const size_t* token_counts,
+                                           uint32_t context_window, uint32_t reprime_interval, uint32_t bos) {
+    if (cz_dead(s)) return CZ_ERR_STATE;
+    if (!s || !payloads || !lens || !token_counts || n_streams == 0) { cz_set_error("cz_decode_begin_batch: null argument / no streams"); return CZ_ERR_ARG; }
+    HIPCHK(hipSetDevice(s->device));
+    s->run_off.clear();
+    const size_t cap = (size_t)s->max_streams, G = (n_streams + cap - 1) / cap;
+    if (G > (size_t)std::max(1, s->max_lanes)) {
+        cz_set_error("a sliced decode keeps every lock-step group resident: %zu streams need %zu lanes of %d streams, max_lanes is %d", n_streams, G, s->max_streams, s->max_lanes);
+        return CZ_ERR_UNSUPPORTED;
+    }
+    while (s->lanes.size() + 1 < G) { cz_session* c = nullptr; CZCHK(make_lane(s, &c)); s->lanes.push_back(c); }
+    s->run_off.assign(G + 1, 0);
+    for (size_t g = 0; g < G; ++g) s->run_off[g + 1] = s->run_off[g] + n_streams / G + (g < n_streams % G ? 1 : 0);
+    const bool rw = s->backend == CZ_BACKEND_RWKV7;
+    const cz_status rc = on_run_groups(s, [&](cz_session* ls, size_t g) {
+        const size_t o = s->run_off[g]; const int cnt = (int)(s->run_off[g + 1] - o);
+        return rw ? cz_rwkv7_decode_begin(ls, cnt, payloads + o, lens + o, token_counts + o, bos)
+                  : decode_llama_begin(ls, cnt, payloads + o, lens + o, token_counts + o, context_window, reprime_interval, bos);
+    });
+    if (rc != CZ_OK) s->run_off.clear();
+    return rc;
+}
+extern "C" cz_status cz_decode_advance(cz_session* s, size_t n_tokens, size_t* position, size_t* remaining) {
+    if (cz_dead(s)) return CZ_ERR_STATE;
+    if (!s) { cz_set_error("cz_decode_advance: null argument"); return CZ_ERR_ARG; }
+    HIPCHK(hipSetDevice(s->device));
+    const bool rw = s->backend == CZ_BACKEND_RWKV7;
+    CZCHK(on_run_groups(s, [&](cz_session* ls, size_t) { return rw ? cz_rwkv7_decode_advance(ls, n_tokens) : decode_llama_advance(ls, n_tokens); }));
+    size_t pos = 0, rem = 0;
+    for (size_t g = 0; g + 1 < s->run_off.size(); ++g) {
+        const DecRun& r = (g == 0 ? s : s->lanes[g - 1])->run;
+        pos = std::max(pos, r.i); rem = std::max(rem, r.max_tc - r.i);
+    }
+    if (position) *position = pos;
+    if (remaining) *remaining = rem;
+    return CZ_OK;
+}
+extern "C" cz_status cz_decode_fetch_batch(cz_session* s, size_t n_streams, uint32_t* const* out_ids) {
+    if (cz_dead(s)) return CZ_ERR_STATE;
+    if (!s || !out_ids) { cz_set_error("cz_decode_fetch_batch: null argument"); return CZ_ERR_ARG; }
+    if (s->run_off.empty() || n_streams != s->run_off.back()) { cz_set_error("cz_decode_fetch_batch: %zu streams, the decode in progress has %zu", n_streams, s->run_off.empty() ? (size_t)0 : s->run_off.back()); return CZ_ERR_ARG; }
+    HIPCHK(hipSetDevice(s->device));
+    const bool rw = s->backend == CZ_BACKEND_RWKV7;
+    return on_run_groups(s, [&](cz_session* ls, size_t g) { return rw ? cz_rwkv7_decode_fetch(ls, out_ids + s->run_off[g]) : decode_llama_fetch(ls, out_ids + s->run_off[g]); });
+}
+extern "C" cz_status cz_decode_end(cz_session* s) {
+    if (!s) return CZ_ERR_ARG;
+    for (size_t g = 0; g + 1 < s->run_off.size(); ++g) (g == 0 ? s : s->lanes[g - 1])->run.active = false;
+    s->run_off.clear();
+    return CZ_OK;
+}
+extern "C" cz_status cz_encode_tokens_range_batch(cz_session* s, size_t n_streams, const uint32_t* const* ids, const size_t* n, uint32_t context,
+                                                  uint32_t reprime_interval, const size_t* i_begin, const size_t* i_end,
+                                                  uint32_t* const* out_c_lo, uint32_t* const* out_c_hi) {
+    if (cz_dead(s)) return CZ_ERR_STATE;
+    if (!s || !ids || !n || !i_begin || !i_end || !out_c_lo || !out_c_hi) { cz_set_error("cz_encode_tokens_range_batch: null argument"); return CZ_ERR_ARG; }
+    if (s->backend != CZ_BACKEND_SMOLLM) {
+        cz_set_error("cz_encode_tokens_range_batch: the rwkv7 backend has no re-prime (src/main.rs:2275), so a stream's tokens cannot be evaluated independently");
+        return CZ_ERR_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(s->device));
+    return encode_llama(s, n_streams, ids, n, context, reprime_interval, i_begin, i_end, out_c_lo, out_c_hi);
 }
 
 // a second, independent session on the SAME device tensors (the reference loads the model a second time for that, src/main.rs:1943-1956)

@@ -100,6 +100,28 @@ cz_status cz_decode_tokens_batch(cz_session* s, size_t n_streams, const uint8_t*
                                  const size_t* token_counts, uint32_t context_window, uint32_t reprime_interval,
                                  uint32_t bos, uint32_t* const* out_ids);
 
+/* Segment-sharded encode of ONE stream: like cz_encode_tokens_batch, but only the coded tokens i in [i_begin[k], i_end[k]) of
+ * stream k are evaluated, and out_c_lo[k] / out_c_hi[k] (room for i_end[k] - i_begin[k] entries) are indexed by i - i_begin[k].  A re-prime
+ * segment of the reference's schedule (src/main.rs:2280-2284) depends on token ids only, so ranks can each take a range of the same file and
+ * send their pairs to the rank that runs cz_ac_encode_pairs and writes the single .canz (src/main.rs:2358-2376).  Any range is legal; ranges
+ * cut at multiples of reprime_interval cost no duplicated rows.  smollm backend only (RWKV7 has no re-prime: one stream does not shard). */
+cz_status cz_encode_tokens_range_batch(cz_session* s, size_t n_streams, const uint32_t* const* ids, const size_t* n,
+                                       uint32_t context, uint32_t reprime_interval, const size_t* i_begin, const size_t* i_end,
+                                       uint32_t* const* out_c_lo, uint32_t* const* out_c_hi);
+
+/* The decode loop of decode_file (src/main.rs:2528-2541, 2621-2628 / 2812-2834) in slices, e.g. to report progress the way the reference's
+ * progress bar does (:2354) or to bound the latency of one call: begin copies the payloads and steps BOS; every advance decodes up to
+ * n_tokens more tokens per stream in lock-step (*position = tokens decoded so far of the longest stream, *remaining = what is left of it;
+ * either may be NULL); fetch copies the ids decoded so far (token_count + 1 per stream, BOS first; entries past the decoded position are
+ * unspecified); end releases the slot.  KV cache / recurrent state, arithmetic-decoder states and ids stay in HBM between the calls, so
+ * every lock-step group must stay resident: n_streams <= max_streams x lanes (CZ_ERR_UNSUPPORTED otherwise).  cz_decode_tokens_batch is
+ * begin + advance(everything) + fetch + end.  One decode in progress per session. */
+cz_status cz_decode_begin_batch(cz_session* s, size_t n_streams, const uint8_t* const* payloads, const size_t* lens,
+                                const size_t* token_counts, uint32_t context_window, uint32_t reprime_interval, uint32_t bos);
+cz_status cz_decode_advance(cz_session* s, size_t n_tokens, size_t* position, size_t* remaining);
+cz_status cz_decode_fetch_batch(cz_session* s, size_t n_streams, uint32_t* const* out_ids);
+cz_status cz_decode_end(cz_session* s);
+
 /* cross_entropy_bits_over_span (src/main.rs:1725-1751, floor-softmax :758-766), the scorer next to the coder on the same forward:
  * prime = last min(511 - min(n_hint, 511), n_history) ids of history ++ first min(n_hint, 511) ids of hint; bits = sum over the targets of
  * -log2(max(p(target | prime, earlier targets), 1e-300)).  Teacher-forced and batched on the GPU (one causal forward per span, all spans
@@ -128,6 +150,12 @@ typedef struct cz_header {
 size_t cz_write_header_v2(const cz_header* h, const uint8_t* model_file_repr, uint8_t* out, size_t cap);   /* :594-611; 0 = cap too small */
 cz_status cz_read_header_v2(const uint8_t* buf, size_t len, cz_header* h, size_t* repr_off, size_t* consumed); /* :613-646 */
 uint32_t cz_flags_pack(int agent_used, int agent_mock, int gates_present, uint32_t agent_chunk);            /* :247-255 */
+/* Producer mark.  The reference leaves bits 1..15 of reserved_flags "reserved (0)" (src/main.rs:240-243; it defines bits 0-2 and reads
+ * nothing else, :256-259).  A payload only decodes with the logits arithmetic that encoded it, and this library's arithmetic (canonical
+ * chunk-64 f32 order, own expf: DESIGN.md) is not candle's, although the container is the same.  Files written through this library set
+ * bit 15, so that a decoder can tell them from candle-produced ones of the same weights: the CLI refuses a file without the mark unless
+ * --force-mismatch, next to the model/tokenizer hash checks of src/main.rs:2448-2459.  The reference's reader ignores the bit. */
+#define CZ_FLAG_PRODUCER_HIP (1u << 15)
 /* gate section after the header when FLAG_AGENT_GATES is set (src/main.rs:2469-2484): returns bytes to skip */
 cz_status cz_skip_gate_section(const uint8_t* buf, size_t len, size_t* consumed);
 
@@ -140,9 +168,11 @@ cz_status cz_blake3_files_bin16(const char* const* paths, size_t n, uint8_t out[
 typedef struct cz_rwkv_tokenizer cz_rwkv_tokenizer;
 cz_status cz_rwkv_tokenizer_open(const char* vocab_json_path, cz_rwkv_tokenizer** out);
 void cz_rwkv_tokenizer_close(cz_rwkv_tokenizer* t);
-/* plan_rwkv_symbols: ids_out needs room for n_bytes entries; literal escape = vocab + byte */
+/* plan_rwkv_symbols: literal escape = vocab + byte.  ids_out has room for ids_cap entries; n_bytes entries always suffice for a
+ * vocabulary whose ids are unique (every token covers >= 1 byte).  *n_ids is set even when the call fails with CZ_ERR_ARG because
+ * ids_cap is too small (two tokens sharing one id can make the "uncovered tail" of src/main.rs:850-859 longer than n_bytes). */
 cz_status cz_rwkv_plan_symbols(const cz_rwkv_tokenizer* t, const uint8_t* bytes, size_t n_bytes, uint32_t vocab,
-                               uint32_t* ids_out, size_t* n_ids);
+                               uint32_t* ids_out, size_t ids_cap, size_t* n_ids);
 /* rwkv_detok_with_literals: *out malloc'd (cz_free) */
 cz_status cz_rwkv_detok(const cz_rwkv_tokenizer* t, const uint32_t* ids, size_t n, uint32_t vocab, uint8_t** out, size_t* out_len);
 

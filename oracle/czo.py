@@ -436,3 +436,90 @@ def to_bf16(x):
     """round-to-nearest-even f32 -> bf16 bits"""
     u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
     return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+# ---------------------------------------------------------------- RWKV "World" tokenizer + symbol planning (SURVEY §8 row R-3)
+class WorldTokenizer:
+    """Restatement of `Tokenizer` (candle_rwkv7/src/models/rwkv7.rs:546-610).  Pure Python: byte/dict work on small inputs.
+
+    Tokenizer::new (:553-573): the vocabulary file is a JSON object {string: id}; every key is taken as its UTF-8 bytes.
+    `table[s0][s1]` lists the tokens of length >= 2 starting with bytes (s0, s1) in DESCENDING id order (the loop runs
+    `(0..1+max_idx).rev()`), `good[s0]` is the set of second bytes that have an entry.  Two keys with the same id: the
+    reference keeps whichever its HashMap iteration meets last (unspecified); this restatement and the library keep the
+    LAST one in file order."""
+
+    def __init__(self, path):
+        import json
+        with open(path, "rb") as f:
+            pairs = json.loads(f.read().decode("utf-8"), object_pairs_hook=list)
+        self.token2idx = {}
+        for k, v in pairs:                                           # serde_json into HashMap<String, u32>: the last duplicate key wins
+            self.token2idx[k.encode("utf-8")] = int(v)               # key.into_bytes()                                 (:556)
+        self.idx2token = {}
+        for k, v in pairs:
+            kb = k.encode("utf-8")
+            if self.token2idx.get(kb) == int(v):
+                self.idx2token[int(v)] = kb                          # (:557)
+        max_idx = max(self.token2idx.values(), default=0)            # (:558)
+        self.table = {}
+        self.good = {}
+        for idx in range(max_idx, -1, -1):                           # (0..(1 + max_idx)).rev()                         (:561)
+            s = self.idx2token.get(idx)
+            if s is None:
+                continue
+            if len(s) >= 2:                                          # (:563-567)
+                self.table.setdefault((s[0], s[1]), []).append(s)
+                self.good.setdefault(s[0], set()).add(s[1])
+
+    def decode_bytes(self, tokens):                                  # (:575-579): unknown ids contribute nothing
+        return b"".join(self.idx2token.get(int(t), b"") for t in tokens)
+
+    def encode_bytes(self, data: bytes):                             # (:586-607); raises ValueError where the reference returns Err
+        tokens = []
+        i = 0
+        n = len(data)
+        while i < n:
+            s = data[i:i + 1]
+            if i + 1 < n and data[i + 1] in self.good.get(data[i], ()):
+                for cand in self.table[(data[i], data[i + 1])]:
+                    if data.startswith(cand, i):                      # bytes[i..].starts_with(table_elem): first hit wins
+                        s = cand
+                        break
+            i += len(s)
+            tok = self.token2idx.get(s)
+            if tok is None:
+                raise ValueError(f"Tokenizer vocabulary missing byte sequence: {list(s)}")
+            tokens.append(tok)
+        return tokens
+
+
+def plan_rwkv_symbols(data: bytes, tok: WorldTokenizer, vocab_size: int):
+    """src/main.rs:833-870 (the symbols only; the offsets the reference also builds are unused with the agent off)"""
+    try:
+        symbols = list(tok.encode_bytes(data))
+    except ValueError:
+        return [vocab_size + b for b in data]                        # complete fallback: literal bytes                 (:863-868)
+    current_offset = 0
+    for sid in symbols:
+        current_offset += len(tok.decode_bytes([sid]))               # (:843-848)
+    if current_offset < len(data):                                   # uncovered tail -> literals                       (:850-859)
+        symbols += [vocab_size + data[i] for i in range(current_offset, len(data))]
+    return symbols
+
+
+def rwkv_detok_with_literals(tok: WorldTokenizer, symbols, vocab_size: int) -> bytes:
+    """src/main.rs:872-895"""
+    out = bytearray()
+    seq = []
+    for s in symbols:
+        s = int(s)
+        if s < vocab_size:
+            seq.append(s)
+        else:
+            if seq:
+                out += tok.decode_bytes(seq)
+                seq = []
+            out.append((s - vocab_size) & 0xFF)                      # `byte_value as u8`
+    if seq:
+        out += tok.decode_bytes(seq)
+    return bytes(out)

@@ -55,6 +55,56 @@ def test_self_test_roundtrip_rwkv7_literals_and_smollm_ids(tmp_path):
     assert r.returncode != 0 and "model hash mismatch" in r.stderr
 
 
+def test_context_window_checks():
+    """context 0 is refused like the reference's empty-history error; context < 512 desynchronises encoder and decoder in the reference
+    (src/main.rs:1935 vs :2506) and is announced loudly"""
+    sys.path.insert(0, ROOT)
+    from candlezip_amd import cli
+    import io, contextlib
+    a = cli.build_parser().parse_args(["--context", "0", "compress", "a", "b"])
+    with pytest.raises(SystemExit, match="context must be > 0"):
+        cli._check_window(a)
+    a = cli.build_parser().parse_args(["--context", "300", "compress", "a", "b"])
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err):
+        cli._check_window(a)
+    assert "will NOT decode" in err.getvalue()
+    a = cli.build_parser().parse_args(["--backend", "rwkv7", "--context", "0", "compress", "a", "b"])
+    cli._check_window(a)                                                            # RWKV7 never re-primes: the window is unused
+
+
+@pytest.mark.gpu
+def test_producer_mark_guards_foreign_archives(tmp_path):
+    """a .canz without this build's producer mark (reserved_flags bit 15) — e.g. one written by the candle reference for the same weights — is
+    refused unless --force-mismatch: its payload only decodes with the arithmetic that wrote it"""
+    ids = np.random.default_rng(1).integers(0, 49152, 40).astype("<u4")
+    idf = tmp_path / "tok.ids"; ids.tofile(idf)
+    inp = tmp_path / "in.txt"; inp.write_bytes(b"x" * 100)
+    out = tmp_path / "o.canz"; back = tmp_path / "back.ids"
+    r = _run("--synthetic", "1", "--token-ids", str(idf), "compress", str(inp), str(out))
+    assert r.returncode == 0, r.stderr
+    blob = bytearray(out.read_bytes())
+    import candlezip_amd as cz
+    h, _, _ = cz.read_header(bytes(blob))
+    assert h.reserved_flags == (512 << 16) | cz.FLAG_PRODUCER_HIP
+    k = bytes(blob).index(int(h.reserved_flags).to_bytes(4, "little"))
+    blob[k:k + 4] = (512 << 16).to_bytes(4, "little")                              # what the reference writes for this file (flags_pack, :247-255)
+    foreign = tmp_path / "foreign.canz"; foreign.write_bytes(bytes(blob))
+    r = _run("--synthetic", "1", "--token-ids", str(idf), "decompress", str(foreign), str(back))
+    assert r.returncode != 0 and "producer mismatch" in r.stderr
+    r = _run("--synthetic", "1", "--token-ids", str(idf), "--force-mismatch", "decompress", str(foreign), str(back))
+    assert r.returncode == 0 and "producer mark" in r.stderr and np.array_equal(np.fromfile(back, "<u4"), ids)
+
+
+@pytest.mark.gpu
+def test_self_test_rwkv7_with_world_vocabulary(tmp_path):
+    golden = os.path.join(ROOT, "tests", "golden")
+    src = tmp_path / "fields.c"
+    src.write_bytes(open(os.path.join(golden, "inputs", "fields.c"), "rb").read()[:6000])
+    r = _run("--backend", "rwkv7", "--synthetic", "7", "--rwkv-tokenizer", os.path.join(golden, "world_vocab_test.json"), "self-test", str(src))
+    assert r.returncode == 0 and "Roundtrip OK" in r.stdout, r.stderr + r.stdout
+
+
 @pytest.mark.gpu
 def test_self_test_text_roundtrip_with_in_process_bpe(tmp_path):
     """the whole drop-in path on text: tokenizer.json (in-process byte-level BPE) -> ids -> GPU encode -> .canz -> GPU decode -> text"""

@@ -1,0 +1,163 @@
+"""Round-2 GPU parity tests through the C ABI:
+ * range (segment-sharded) encode == the matching slice of the whole-stream encode, for arbitrary ranges;
+ * the decode loop in slices (begin / advance / fetch / end) == the one-shot decode, for both back-ends, graph replay and eager, several lanes;
+ * the SmolLM2-135M shape on >= 1100 REAL token ids (the reference's own SmolLM2 tokenisation of asyoulik.txt, tests/golden/tokens_asyoulik.u16)
+   across two re-prime boundaries: pairs + payload vs the oracle, then a three-lane decode;
+ * BASELINE config 4: Canterbury files through the RWKV7 recurrent-state path (World tokenizer fixture), pairs vs the oracle on a prefix at
+   the 0.1B shape and a byte-exact round trip of the whole files."""
+import json
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def cz():
+    import candlezip_amd as m
+    m.lib()
+    return m
+
+
+def test_range_encode_equals_slices_of_the_full_encode(cz):
+    g = cz.Session("smollm", cz.tiny_llama_config(), seed=11, embed_std=0.05, max_streams=4)
+    rng = np.random.default_rng(3)
+    streams = [np.concatenate([[0], rng.integers(0, 512, n)]).astype(np.uint32) for n in (1700, 600, 40)]
+    full = g.encode_tokens_batch(streams, 512, 512)
+    for ranges in ([(0, 1700), (0, 600), (0, 40)], [(512, 1024), (100, 101), (0, 0)], [(1024, 1700), (511, 600), (39, 40)], [(700, 1300), (0, 513), (5, 33)]):
+        part = g.encode_tokens_range_batch(streams, ranges, 512, 512)
+        for (b, e), (lo, hi), (flo, fhi) in zip(ranges, part, full):
+            assert lo.size == e - b and np.array_equal(lo, flo[b:e]) and np.array_equal(hi, fhi[b:e]), (b, e)
+    # another schedule (reprime every 256 once the window is full) and the same stream given twice with different ranges
+    full = g.encode_tokens_batch(streams[:1], 300, 256)[0]
+    a, b_ = g.encode_tokens_range_batch([streams[0], streams[0]], [(0, 768), (768, 1700)], 300, 256)
+    assert np.array_equal(np.concatenate([a[0], b_[0]]), full[0]) and np.array_equal(np.concatenate([a[1], b_[1]]), full[1])
+    with pytest.raises(cz.CandlezipError):
+        g.encode_tokens_range_batch(streams[:1], [(10, 1701)], 512, 512)
+    with pytest.raises(cz.CandlezipError, match="empty history"):
+        g.encode_tokens(streams[0], 0, 512)                                        # context 0: the reference fails at its first re-prime
+    g.close()
+    r = cz.Session("rwkv7", cz.tiny_rwkv7_config(), seed=9, embed_std=0.05, max_streams=2)
+    with pytest.raises(cz.CandlezipError, match="no re-prime"):
+        r.encode_tokens_range_batch(streams[:1], [(0, 10)])
+    r.close()
+
+
+@pytest.mark.parametrize("no_graph", [0, 1])
+def test_sliced_decode_equals_one_shot_smollm(cz, no_graph):
+    g = cz.Session("smollm", cz.tiny_llama_config(), seed=11, embed_std=0.05, max_streams=3)
+    g.debug_set("max_lanes", 3); g.debug_set("no_graph", no_graph)
+    rng = np.random.default_rng(8)
+    lens = [1400, 700, 1, 1203, 0, 512, 513, 90]                                   # 8 streams -> 3 lock-step groups, one per lane
+    streams = [np.concatenate([[0], rng.integers(0, 512, n)]).astype(np.uint32) for n in lens]
+    pays = [cz.ac_encode_pairs(lo, hi)[0] for lo, hi in g.encode_tokens_batch(streams)]
+    ref = g.decode_tokens_batch(pays, lens)
+    for s_, o in zip(streams, ref):
+        assert np.array_equal(s_, o)
+    g.decode_begin_batch(pays, lens)
+    seen = 0
+    for step in (1, 510, 1, 1, 300, 10 ** 9):                                      # slices that straddle the re-prime at i = 512 and the one at 1024
+        pos, rem = g.decode_advance(step)
+        seen = min(seen + step, max(lens))
+        assert pos == seen and rem == max(lens) - seen
+        part = g.decode_fetch_batch()
+        for s_, o, n in zip(streams, part, lens):
+            k = min(pos, n)
+            assert np.array_equal(o[: k + 1], s_[: k + 1])
+    g.decode_end()
+    with pytest.raises(cz.CandlezipError, match="no decode in progress"):
+        g.decode_advance(1)
+    # more groups than lanes cannot stay resident
+    g.debug_set("max_lanes", 2)
+    with pytest.raises(cz.CandlezipError, match="resident"):
+        g.decode_begin_batch(pays, lens)
+    assert all(np.array_equal(a, b) for a, b in zip(g.decode_tokens_batch(pays, lens), ref))   # the one-shot path still cycles groups over lanes
+    g.close()
+
+
+def test_sliced_decode_equals_one_shot_rwkv7(cz):
+    g = cz.Session("rwkv7", cz.tiny_rwkv7_config(), seed=9, embed_std=0.05, max_streams=2)
+    g.debug_set("max_lanes", 2)
+    rng = np.random.default_rng(4)
+    lens = [90, 31, 64]
+    streams = [np.concatenate([[0], rng.integers(0, 512 + 256, n)]).astype(np.uint32) for n in lens]
+    pays = [cz.ac_encode_pairs(lo, hi)[0] for lo, hi in g.encode_tokens_batch(streams)]
+    g.decode_begin_batch(pays, lens)
+    for step in (7, 50, 1000):
+        g.decode_advance(step)
+    outs = g.decode_fetch_batch()
+    g.decode_end()
+    for s_, o in zip(streams, outs):
+        assert np.array_equal(s_, o)
+    g.close()
+
+
+def test_smollm2_135m_shape_real_ids_across_two_reprimes(cz, czo, golden):
+    """>= 1100 ids of the reference's own asyoulik.txt tokenisation at the BASELINE shape: the re-primes at i = 512 and i = 1024 are crossed
+    against the oracle (pairs and payload bytes), then the payloads are decoded on three lanes"""
+    ids = np.concatenate([[0], np.fromfile(os.path.join(golden, "tokens_asyoulik.u16"), "<u2")[:1150]]).astype(np.uint32)
+    g = cz.Session("smollm", cz.smollm2_135m_config(), seed=0x5EED, embed_std=0.02, max_streams=2)
+    o = czo.SmolLmSession(czo.smollm2_135m_config(), seed=0x5EED, embed_std=0.02)
+    payload, clo, chi, zw = o.encode_tokens(ids, 512, 512)
+    lo, hi = g.encode_tokens(ids, 512, 512)
+    assert np.array_equal(lo, clo) and np.array_equal(hi, chi)
+    pay, zw2 = cz.ac_encode_pairs(lo, hi)
+    assert pay == payload and zw2 == zw
+    g.debug_set("max_lanes", 3)
+    toks = np.fromfile(os.path.join(golden, "tokens_asyoulik.u16"), "<u2")
+    streams = [ids, np.concatenate([[0], toks[2000:2700]]).astype(np.uint32), ids[:600], np.concatenate([[0], toks[5000:5031]]).astype(np.uint32), ids]
+    coded = [cz.ac_encode_pairs(*p) for p in g.encode_tokens_batch(streams, 512, 512)]
+    assert coded[0][0] == payload and coded[4][0] == payload
+    outs = g.decode_tokens_batch([p for p, _ in coded], [s.size - 1 for s in streams], 512, 512, 0)      # 5 streams, groups of 2 -> three lanes
+    assert np.array_equal(outs[0], o.decode_tokens(payload, ids.size - 1, 512, 512, 0))                 # same ids as the CPU decoder, decodable or not
+    for s_, out, (_, z) in zip(streams, outs, coded):
+        if z == 0:                                                                                      # (a zero-width interval makes a stream undecodable)
+            assert np.array_equal(out, s_)
+    assert sum(1 for _, z in coded if z == 0) >= 3
+    g.close(); o.close()
+
+
+def test_canterbury_through_the_rwkv7_path(cz, czo, golden):
+    """BASELINE config 4 (--backend rwkv7 on Canterbury, recurrent-state kernels): alice29 / asyoulik / fields.c -> World symbols -> lock-step
+    RWKV7-0.1B-shaped encode -> payloads -> lock-step decode -> bytes; the first chunk's leading symbols are checked against the oracle"""
+    wt = cz.WorldTokenizer(os.path.join(golden, "world_vocab_test.json"))
+    g = cz.Session("rwkv7", cz.rwkv7_0b1_config(), seed=3, embed_std=0.02, max_streams=16)
+    g.debug_set("max_lanes", 2)
+    V = g.vocab_size()
+    chunks = []
+    for name in ("alice29.txt", "asyoulik.txt", "fields.c"):
+        data = open(os.path.join(golden, "inputs", name), "rb").read()
+        chunks += [data[o:o + 8192] for o in range(0, len(data), 8192)][:7]                 # 7 + 7 + 2 chunks of 8 KiB
+    chunks.append(bytes(range(256)) * 2 + b"\xff\xfe tail")                                     # not in the vocabulary: every byte a literal symbol
+    streams = [np.concatenate([[0], wt.plan_symbols(c, V)]).astype(np.uint32) for c in chunks]
+    assert streams[-1][1:].min() >= V and max(s[1:].max() for s in streams[:-1]) < V
+    pairs = g.encode_tokens_batch(streams)
+    pays = [cz.ac_encode_pairs(lo, hi) for lo, hi in pairs]
+    assert all(zw == 0 for _, zw in pays)
+    outs = g.decode_tokens_batch([p for p, _ in pays], [s.size - 1 for s in streams])
+    for c, s_, out in zip(chunks, streams, outs):
+        assert np.array_equal(out, s_) and wt.detok(out[1:], V) == c
+    assert g.debug_get("cdf_fallback_rows") == 0
+    # oracle parity on real symbols: the first 320 symbols of alice29's first chunk and the literal-only chunk's first 40
+    o = czo.Rwkv7Session(czo.rwkv7_0b1_config(), seed=3, embed_std=0.02)
+    for k, n in ((0, 320), (len(chunks) - 1, 40)):
+        ref_p, clo, chi, _ = o.encode_tokens(streams[k][: n + 1])
+        assert np.array_equal(pairs[k][0][:n], clo) and np.array_equal(pairs[k][1][:n], chi), k
+    g.close(); o.close(); wt.close()
+
+
+def _corpus(*argv, env=None):
+    r = subprocess.run([sys.executable, "-m", "candlezip_amd.corpus", *argv], cwd=ROOT, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-1000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_corpus_driver_rwkv7_backend(golden):
+    files = [os.path.join(golden, "inputs", n) for n in ("fields.c", "asyoulik.txt")]
+    d = _corpus("--backend", "rwkv7", "--synthetic", "5", "--rwkv-tokenizer", os.path.join(golden, "world_vocab_test.json"), "--chunk-bytes", "16384",
+                "--max-streams", "16", *files)
+    assert d["backend"] == "rwkv7" and d["roundtrip_failures"] == [] and d["chunks"] == 1 + 8 and d["lossy_utf8_chunks"] == 0 and d["tokens"] > 70000
