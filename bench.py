@@ -54,7 +54,7 @@ FUNCTIONS = {
 }
 
 
-def pmc_traffic(prefix):
+def pmc_traffic(prefix, tokens=1536):
     """HBM bytes per launch of a kernel function from the committed rocprofv3 --pmc passes (profiles/r*_pmc*_{FETCH,WRITE}_SIZE_pmc.json,
     made by tools/prof_summary.py from separate FETCH_SIZE / WRITE_SIZE runs).  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
     counts 128-B requests of wide coalesced reads at 64 B, so it is doubled (MI355X_MICROARCH.md, "HBM").  The newest file that holds
@@ -62,7 +62,9 @@ def pmc_traffic(prefix):
     import glob
     tot = 0.0; notes = []
     for counter, scale in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc*_{counter}_pmc.json")), reverse=True)
+        # the pass of the same length as the eager profiling pass first (r<round>_pmc<tokens>_...), newest round first; then any other
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc{tokens}_{counter}_pmc.json")), reverse=True) + \
+            sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc*_{counter}_pmc.json")), reverse=True)
         hit = None
         for f in files:
             d = json.load(open(f))
@@ -209,6 +211,7 @@ def main():
     ap.add_argument("--window", type=int, default=1024, help="tokens per stream and step")
     ap.add_argument("--no-graph", action="store_true", help="launch the decode step eagerly (one AQL packet per submission: for rocprofv3 --pmc)")
     ap.add_argument("--no-events", action="store_true", help="no HIP-event timing inside the timed region (for rocprofv3 --pmc)")
+    ap.add_argument("--step-sync", action="store_true", help="with --no-graph: synchronise after every decode step, so that launches never queue up (rocprofv3 --pmc, DESIGN.md §9)")
     ap.add_argument("--kv-ctx-cap", type=int, default=0, help="tuning: positions per stream in the KV cache (0 = library default 2048)")
     ap.add_argument("--profile-tokens", type=int, default=1536, help="tokens/stream of the untimed eager per-family profiling pass (0 = skip)")
     ap.add_argument("--context", type=int, default=512)
@@ -241,6 +244,8 @@ def main():
     sess.debug_set("max_lanes", groups)
     if args.no_graph:
         sess.debug_set("no_graph", 1)
+    if args.step_sync:
+        sess.debug_set("step_sync", 1)
     if args.kv_ctx_cap:
         sess.debug_set("kv_ctx_cap", args.kv_ctx_cap)
     for kv in args.debug_set:
@@ -320,7 +325,7 @@ def main():
             else:
                 ach = st["bytes"] / (ms * 1e-3) / 1e9 if ms else 0.0
                 r = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5)}
-            traffic, tnote = pmc_traffic(prefix)
+            traffic, tnote = pmc_traffic(prefix, args.profile_tokens)
             n = max(st["launches"], 1)
             r.update({"traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": tnote, "kernel": fn + " (all instantiations)", "families": fams,
                       "algorithmic_per_launch": round((st["flops"] if bound == "mfma" else st["bytes"]) / n), "algorithmic_unit": "flop" if bound == "mfma" else "bytes",

@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // QK^T is computed once; exact two-sweep softmax (max, then e and canonical row sums, then p = e/sum).
 #define V2_KS 68
 #define V2_VS 80
+#define V2_QS 20                        // floats per lane of the LDS copy of the Q operand (16 + 4: the four ds_read_b128 of a wave hit distinct banks)
 template <int REP, int NI>
 __global__ __launch_bounds__(256, (REP * NI <= 48 ? 2 : 1)) void attention_v2_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
                                                               const cz_seq_desc* __restrict__ descs, size_t kv_off, const int* __restrict__ pos_dev) {
@@ -190,14 +191,21 @@ __global__ __launch_bounds__(256, (REP * NI <= 48 ? 2 : 1)) void attention_v2_ke
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const int row_base = sd.row0 + tile * 16;
-    // A operand of QK^T: lane (i = li, g = lg) holds Q[row i][head][d = 4t + g]
-    float qreg[REP][16];
+    // A operand of QK^T: lane (i = li, g = lg) holds Q[row i][head][d = 4t + g].  Where the score tiles alone fill most of the register
+    // file (REP * NI >= 48: 192 VGPRs of S) the operand lives in LDS instead — lane-contiguous, so a chunk re-reads it with four
+    // ds_read_b128 per head — and the kernel stays under 256 VGPRs without scratch (it spilled 64 registers per lane before).
+    constexpr bool QLDS = REP * NI >= 48;
+    __shared__ __attribute__((aligned(16))) float Qs[QLDS ? REP * 64 * V2_QS : 4];
+    float qreg[QLDS ? 1 : REP][16];
 #pragma unroll
     for (int rt = 0; rt < REP; ++rt) {
         const bool valid = li < rows_here;
         const float* qp = Q + (size_t)(row_base + (valid ? li : 0)) * ldq + (kvh * REP + rt) * 64 + lg;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) { const float v = qp[4 * t]; qreg[rt][t] = valid ? v : 0.0f; }
+        for (int t = 0; t < 16; ++t) {
+            const float v = valid ? qp[4 * t] : 0.0f;
+            if (QLDS) { if (wave == 0) Qs[(rt * 64 + lane) * V2_QS + t] = v; } else qreg[rt][t] = v;
+        }
     }
     f32x4 S[NI][REP];
     // K / V chunk loads: one block per CU and one wave per SIMD leave nothing else to hide a miss behind, so the NEXT chunk's four
@@ -242,14 +250,26 @@ __global__ __launch_bounds__(256, (REP * NI <= 48 ? 2 : 1)) void attention_v2_ke
             if (c + 1 < nch) load_k(c + 1, pre);                       // in flight during the MFMAs below
             float kb[16];
             const float* kbp = stage + (wave * 16 + li) * V2_KS + lg;
+            if (!QLDS) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) kb[t] = kbp[4 * t];
+                for (int t = 0; t < 16; ++t) kb[t] = kbp[4 * t];
+            }
             const int key = c * 64 + wave * 16 + li;
 #pragma unroll
             for (int rt = 0; rt < REP; ++rt) {
                 f32x4 acc = f32x4{0, 0, 0, 0};
+                if (QLDS) {                                                 // operands in pieces of four k-steps: 8 live registers instead of 32
+                    const f32x4* qp4 = reinterpret_cast<const f32x4*>(Qs + (rt * 64 + lane) * V2_QS);
 #pragma unroll
-                for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qreg[rt][t], kb[t], acc, 0, 0, 0);
+                    for (int t4 = 0; t4 < 4; ++t4) {
+                        const f32x4 q = qp4[t4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q[t], kbp[4 * (4 * t4 + t)], acc, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qreg[rt][t], kb[t], acc, 0, 0, 0);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {                               // C/D: col = li -> key ; row = 4*lg + r -> query row
                     const int qr = 4 * lg + r;
@@ -341,14 +361,16 @@ __global__ __launch_bounds__(256, (REP * NI <= 48 ? 2 : 1)) void attention_v2_ke
             if (c + 1 < nch) load_v(c + 1, pre);
             float vb[16];
             const float* vbp = stage + lg * V2_VS + wave * 16 + li;          // B[k = 4t + lg][j = li] = V[key][col]
+            if (!QLDS) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) vb[t] = vbp[4 * t * V2_VS];
+                for (int t = 0; t < 16; ++t) vb[t] = vbp[4 * t * V2_VS];
+            }
 #pragma unroll
             for (int rt = 0; rt < REP; ++rt) {
                 const float* pa = Et + (rt * 16 + li) * V2_KS + lg;          // A[i = li][k = 4t + lg] = P[row][key]
                 f32x4 acc = f32x4{0, 0, 0, 0};
 #pragma unroll
-                for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * t], vb[t], acc, 0, 0, 0);
+                for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * t], QLDS ? vbp[4 * t * V2_VS] : vb[t], acc, 0, 0, 0);
                 if (c == 0) tot[rt] = acc;
                 else
 #pragma unroll

@@ -362,13 +362,18 @@ static cz_status llama_step_fast(cz_session* s, int B, int pos, int max_nk) {
     for (int l = 0; l < c.n_layers; ++l) {
         const LlamaModel::Layer& y = m.L[l];
         const size_t kv_off = (size_t)l * s->kv_layer_stride;
+        if (!(s->dbg_skip & 2)) {
         s->prof_begin(PK_DEC_GEMM_QKV);                                                    // RMSNorm(ln1) fused into the A load
         HIPCHK(cz_launch_dec_gemm_qkv(st, x, d, dec(y.wqkv), q, d, B, d, c.n_heads, c.n_kv_heads, s->step_roped, kv_off, s->pos_dev, m.rope_cos, m.rope_sin,
                                       y.ln1, c.rms_eps));
         s->prof_end(2.0 * B * (double)nq * d, (double)nq * d * 2);
+        }
+        if (!(s->dbg_skip & 1)) {
         s->prof_begin(PK_DEC_ATTN);
         HIPCHK(cz_launch_dec_attn(st, q, d, att, d, s->step_seqd, B, max_nk, c.n_heads, c.n_kv_heads, kv_off, s->pos_dev));
         s->prof_end(4.0 * 64 * c.n_heads * (double)B * (pos + 1), 2.0 * B * (double)(pos + 1) * kvd * 4);
+        }
+        if (s->dbg_skip & 2) continue;
         s->prof_begin(PK_DEC_GEMM); HIPCHK(cz_launch_dec_gemm_plain(st, att, d, dec(y.wo), x, d, x, B, d, d, nullptr, 0.0f)); s->prof_end(2.0 * B * (double)d * d, (double)d * d * 2);
         // wide projections (gate|up, lm_head) have many column blocks: normalise once instead of once per block
         s->prof_begin(PK_DEC_NORM); HIPCHK(cz_launch_dec_rmsnorm(st, x, d, y.ln2, xn, d, B, d, c.rms_eps)); s->prof_end(0, (double)B * d * 8);
@@ -745,6 +750,7 @@ static cz_status decode_llama_advance(cz_session* s, size_t n) {
                 HIPCHK(hipMemcpyAsync(s->tok.p, s->step_sym, (size_t)B * 4, hipMemcpyDeviceToDevice, s->stream));
                 CZCHK(llama_step(s, B, (int)index_pos));
             }
+            if (s->step_sync) HIPCHK(hipStreamSynchronize(s->stream));    // never more than one step of launches queued (profiler runs)
         }
         index_pos += 1;
     }
@@ -890,7 +896,7 @@ static cz_status make_lane(cz_session* p, cz_session** out) {
 }
 static void lane_inherit(const cz_session* s, cz_session* ls) {   // a lane runs with its parent's knobs
     ls->kv_ctx_cap = s->kv_ctx_cap; ls->serial_cdf = s->serial_cdf; ls->decode_v1 = s->decode_v1; ls->no_graph = s->no_graph; ls->force_big_gemm = s->force_big_gemm;
-    ls->max_batch_rows = s->max_batch_rows; ls->logit_batch_rows = s->logit_batch_rows;
+    ls->max_batch_rows = s->max_batch_rows; ls->logit_batch_rows = s->logit_batch_rows; ls->step_sync = s->step_sync; ls->fuse_norm = s->fuse_norm;
 }
 // run `n_streams` streams as groups of <= max_streams on up to max_lanes lanes; group(ls, off, count) processes streams [off, off + count)
 template <class GroupFn>
@@ -1097,6 +1103,72 @@ extern "C" cz_status cz_synchronize(cz_session* s) {
     HIPCHK(hipStreamSynchronize(s->stream));
     return CZ_OK;
 }
+// tuning aid (tools/bench_decode_step.py): `iters` lock-step decode steps of B streams at a FIXED position `pos` (KV cache zeroed), as a
+// replayed hipGraph (use_graph) or eagerly (per-family HIP events when profiling is on).  *ms_total = device time of the iters steps.
+extern "C" cz_status cz_debug_decode_steps(cz_session* s, int B, int pos, int iters, int use_graph, int with_symbol, double* ms_total) {
+    if (!s || !ms_total || s->backend != CZ_BACKEND_SMOLLM || B <= 0 || iters <= 0) { cz_set_error("cz_debug_decode_steps: bad argument"); return CZ_ERR_ARG; }
+    HIPCHK(hipSetDevice(s->device));
+    const cz_llama_config& c = s->llama.cfg;
+    CZCHK(ensure_streams(s, B));
+    if (pos < 0 || pos >= (int)s->ctx_cap) { cz_set_error("pos out of range"); return CZ_ERR_ARG; }
+    CZCHK(s->tok.ensure((size_t)B * 4)); CZCHK(s->decst.ensure(B * sizeof(cz_dec_state))); CZCHK(s->payload.ensure((size_t)B * 64)); CZCHK(s->outids.ensure((size_t)B * 16));
+    HIPCHK(hipMemsetAsync(s->kvcache, 0, (size_t)s->max_streams * s->kv_stream_stride * 4, s->stream));
+    HIPCHK(hipMemsetAsync(s->payload.p, 0x5a, (size_t)B * 64, s->stream));
+    std::vector<cz_dec_state> hs(B);
+    for (int b = 0; b < B; ++b) {
+        cz_dec_state d; memset(&d, 0, sizeof d);
+        d.in = (const uint8_t*)s->payload.p + (size_t)b * 64; d.in_len = 64; d.out_ids = (uint32_t*)s->outids.p + (size_t)b * 4; d.token_count = 0; d.active = 0;   // inactive: state is read, nothing is written
+        hs[b] = d;
+    }
+    HIPCHK(hipMemcpyAsync(s->decst.p, hs.data(), B * sizeof(cz_dec_state), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, (uint32_t*)s->tok.p, 1u, B);
+    hipLaunchKernelGGL(set_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, pos, 0ull);
+    auto one = [&]() -> cz_status {
+        if (with_symbol) HIPCHK(cz_launch_decode_symbol(s->stream, s->step_logits, c.vocab, (cz_dec_state*)s->decst.p, s->step_sym, B, c.vocab, 0, 0ull, s->fallback_dev, nullptr, s->cdf_scratch));
+        return llama_step_fast(s, B, pos, use_graph ? CZ_MAX_CTX : pos + 1);
+    };
+    CZCHK(one());                                                   // sizes every buffer, pages the code in
+    HIPCHK(hipStreamSynchronize(s->stream));
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+    if (use_graph) {
+        const bool prof = s->prof_on; s->prof_on = false;
+        HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+        const cz_status rc = one();
+        const hipError_t e2 = hipStreamEndCapture(s->stream, &g);
+        s->prof_on = prof;
+        if (rc != CZ_OK || e2 != hipSuccess || !g) { cz_set_error("capture failed"); return CZ_ERR_HIP; }
+        HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        HIPCHK(hipGraphLaunch(ge, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    HIPCHK(hipEventRecord(e0, s->stream));
+    for (int i = 0; i < iters; ++i) { if (use_graph) HIPCHK(hipGraphLaunch(ge, s->stream)); else CZCHK(one()); }
+    HIPCHK(hipEventRecord(e1, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_total = ms;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (ge) hipGraphExecDestroy(ge);
+    if (g) hipGraphDestroy(g);
+    return CZ_OK;
+}
+// restrict this session's stream to the CUs of one XCD (experiment: lanes that do not share an L2).  CU-mask bit i belongs to XCD i % 8.
+static cz_status set_stream_xcd(cz_session* s, int xcd, int n_xcd) {
+    if (s->kvcache || s->graph_exec) { cz_set_error("cu_mask_xcd must be set before the first step / decode"); return CZ_ERR_STATE; }
+    hipStream_t ns = nullptr;
+    if (xcd < 0) HIPCHK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+    else {
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 256; ++i) { const int x = i % 8; if (x >= xcd && x < xcd + n_xcd) mask[i / 32] |= 1u << (i % 32); }
+        HIPCHK(hipExtStreamCreateWithCUMask(&ns, 8, mask));
+    }
+    if (s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
+    s->stream = ns;
+    return CZ_OK;
+}
+
 // test/bench knobs (not part of the drop-in surface): 0 = default kernels
 extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     if (!s || !key) return CZ_ERR_ARG;
@@ -1110,6 +1182,10 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "max_lanes")) s->max_lanes = (int)value;
     else if (!strcmp(key, "kv_ctx_cap")) { if (s->kvcache) { cz_set_error("kv_ctx_cap must be set before the first step / decode"); return CZ_ERR_STATE; } s->kv_ctx_cap = (int)value; }
     else if (!strcmp(key, "probe_launch")) s->probe_launch = (int)value;
+    else if (!strcmp(key, "cu_mask_xcd")) return set_stream_xcd(s, (int)(value % 16), (int)(value / 16) + 1);   // value = first_xcd + 16 * (n_xcd - 1); -1: no mask
+    else if (!strcmp(key, "step_sync")) s->step_sync = (int)value;
+    else if (!strcmp(key, "dbg_skip")) s->dbg_skip = (int)value;          // tools/bench_decode_step.py: 1 = no attention, 2 = no GEMMs/norms (timing only; results are garbage)
+    else if (!strcmp(key, "fuse_norm")) s->fuse_norm = (int)value;
     else if (!strcmp(key, "dec_grid_target")) g_dec_grid_target = (int)value;
     else if (!strcmp(key, "dec_mt_max")) g_dec_mt_max = (int)value >= 8 ? 8 : ((int)value >= 4 ? 4 : ((int)value >= 2 ? 2 : 1));
     else if (!strcmp(key, "dec_nw_cap")) g_dec_nw_cap = (int)value < 4 ? 4 : ((int)value > 12 ? 12 : (int)value);

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Tuning aid: lock-step decode steps at a FIXED context length, on one or several concurrent lanes (cz_debug_decode_steps).
+Each config is `name:B=<streams per lane>,L=<lanes>,pos=<context>,x=<0|1: one XCD per lane via a CU-masked stream>,av=<dbg_skip: 1 = no attention, 2 = attention only>,
+fn=<fuse_norm>,g=<1 graph|0 eager>,prof=<1: eager per-family HIP events on lane 0>`.  Prints one JSON line per config."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import candlezip_amd as cz
+
+
+def run_config(parent, cfgs, name, B, L, pos, x, av, fn, g, prof, iters, sym):
+    lib = cz.lib()
+    lib.cz_debug_decode_steps.restype = C.c_int
+    lib.cz_debug_decode_steps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    lanes = [parent.fork() for _ in range(L)]
+    for k, s in enumerate(lanes):
+        s.debug_set("max_lanes", 1)
+        if x:
+            nx = max(1, 8 // L)
+            s.debug_set("cu_mask_xcd", (k * nx) % 8 + 16 * (nx - 1))
+        s.debug_set("dbg_skip", av)
+        s.debug_set("fuse_norm", fn)
+    ms = [0.0] * L; err = []
+
+    def worker(k):
+        out = C.c_double()
+        if prof and k == 0:
+            lanes[k].profile_enable(True)
+        rc = lib.cz_debug_decode_steps(lanes[k].h, B, pos, iters, 0 if (prof and k == 0) else g, sym, C.byref(out))
+        if rc:
+            err.append(lib.cz_last_error().decode())
+        ms[k] = out.value
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(L)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    res = {"config": name, "B": B, "lanes": L, "pos": pos, "xcd_lanes": x, "dbg_skip": av, "fuse_norm": fn, "graph": g, "iters": iters,
+           "ms_per_step_lane": [round(m / iters, 4) for m in ms], "tokens_per_s_device_time": round(L * B * iters / (max(ms) * 1e-3), 1) if not err else None,
+           "wall_s_incl_setup": round(wall, 2), "errors": err}
+    if prof:
+        res["families_us_per_step_lane0"] = {k: round(1e3 * v["total_ms"] / iters, 2) for k, v in lanes[0].profile_read().items()}
+    for s in lanes:
+        s.close()
+    print(json.dumps(res), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--max-streams", type=int, default=128)
+    ap.add_argument("--sym", type=int, default=1, help="include the decode_symbol (CDF) kernel in the step")
+    ap.add_argument("configs", nargs="+")
+    args = ap.parse_args()
+    parent = cz.Session("smollm", cz.smollm2_135m_config(), seed=0x5EED, embed_std=0.02, max_streams=args.max_streams)
+    for c in args.configs:
+        name, _, kv = c.partition(":")
+        d = dict(B=128, L=1, pos=767, x=0, av=0, fn=1, g=1, prof=0)
+        for item in kv.split(","):
+            if item:
+                k, v = item.split("=")
+                d[k] = int(v)
+        run_config(parent, None, name, d["B"], d["L"], d["pos"], d["x"], d["av"], d["fn"], d["g"], d["prof"], args.iters, args.sym)
+    parent.close()
+
+
+if __name__ == "__main__":
+    main()
