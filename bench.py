@@ -239,7 +239,7 @@ def main():
     from candlezip_amd.parallel import lpt_assign
     cfg = cz.tiny_llama_config() if args.tiny else cz.smollm2_135m_config()
     groups = max(1, min(args.lanes, -(-args.streams // args.lane_streams)))
-    per_lane = min(256, -(-args.streams // groups))                       # every lock-step group stays resident on a lane of its own
+    per_lane = min(1024, -(-args.streams // groups))                      # every lock-step group stays resident on a lane of its own
     sess = cz.Session("smollm", cfg, seed=0x5EED, embed_std=0.02, device=local, max_streams=per_lane)
     sess.debug_set("max_lanes", groups)
     if args.no_graph:

@@ -79,6 +79,7 @@ hipError_t cz_launch_dec_gemm_qkv(hipStream_t st, const float* A, int lda, const
                                   const uint16_t* normw, float eps);
 hipError_t cz_launch_dec_gemm_swiglu(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* H, int ldh, int M, int f, int K,
                                      const uint16_t* normw, float eps);
+bool cz_dec_gemm_norm_is_cheap(int K);
 hipError_t cz_launch_dec_gemm_group(hipStream_t st, int nprob, const float* const* A, const int* lda, const uint16_t* const* Wd, float* const* C, const int* ldc,
                                     const int* N, const int* K, int M);
 hipError_t cz_launch_dec_gemm_masked(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* C, int ldc, const float* R, int M, int N, int K,
@@ -86,4 +87,4 @@ hipError_t cz_launch_dec_gemm_masked(hipStream_t st, const float* A, int lda, co
 hipError_t cz_launch_dec_gemm_relusq(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* C, int ldc, int M, int N, int K);
 hipError_t cz_dec_attn_prepare(int max_nk);
 hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nstreams, int max_nk,
-                              int n_heads, int n_kv, size_t kv_off, const int* pos_dev);
+                              int n_heads, int n_kv, size_t kv_off, const int* pos_dev, int out_kq = 1);

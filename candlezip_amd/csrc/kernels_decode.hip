@@ -86,26 +86,64 @@ struct dec_gemm_args {
 };
 
 // MT = 16-row tiles per block (1, 2, 4, 8): one load of the weight slab serves MT x 16 rows.
-template <int EPI, int NORM, int MT>
+// NP = column-tile PAIRS per block (1, 2): a wave's A operand (its K chunk of the block's rows) then serves 2 x NP column tiles — wide
+// lock-step groups (M >= 256) take MT = 2, NP = 2: 32 x 64 outputs per block, half the activation re-reads and twice the MFMA work per
+// operand load of the MT x 1 shape, and still M / 32 x N / 64 blocks (216 for the 768 x 576 o-projection).
+template <int EPI, int NORM, int MT, int NP>
 __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int bx, const int by) {
-    extern __shared__ __attribute__((aligned(16))) float part[];       // [NW][G][2][16][17], G = min(MT, 2) row tiles per reduction round
+    extern __shared__ __attribute__((aligned(16))) float part[];       // [NW][G][NP][2][16][17], G = min(MT, 2) row tiles per reduction round
     __shared__ float nsq[MT * 16][17];
     __shared__ float nm[MT * 16];
     constexpr int G = MT < 2 ? MT : 2;
+    constexpr int WSTRIDE = G * NP * 544;                               // floats of LDS partials per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const int m0 = by * (MT * 16);
-    int n0, n1;
-    if (EPI == EPI_ROPE) {                       // pair (c, c+32) inside one 64-wide head; v heads: two plain tiles of the same head
-        const int head = bx >> 1, j = bx & 1;
-        n0 = head * 64 + j * 16; n1 = n0 + 32;
-    } else if (EPI == EPI_SWIGLU) {              // gate tile + matching up tile
-        n0 = bx * 16; n1 = a.N / 2 + n0;
-    } else {
-        n0 = bx * 32; n1 = n0 + 16;
+    int n0[NP], n1[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int q = bx * NP + p;                   // pair index
+        if (EPI == EPI_ROPE) {                       // pair (c, c+32) inside one 64-wide head; v heads: two plain tiles of the same head
+            const int head = q >> 1, j = q & 1;
+            n0[p] = head * 64 + j * 16; n1[p] = n0[p] + 32;
+        } else if (EPI == EPI_SWIGLU) {              // gate tile + matching up tile
+            n0[p] = q * 16; n1[p] = a.N / 2 + n0[p];
+        } else {
+            n0[p] = q * 32; n1[p] = n0[p] + 16;
+        }
     }
     const int K = a.K, nch = K >> 6;
-    if (NORM) {
+    // NORM == 2 (single round: nch <= NW, MT <= 2): the wave that owns chunk c reads x[rows][chunk c] once, for the sum of squares AND as
+    // its A operand.  The canonical chunk sum p = p + x_k * x_k (product rounded, then added, k ascending) is an MFMA chain with B = 1:
+    // fma(x_k^2, 1, p) rounds x_k^2 + p once, exactly like the add.  No separate pass over the rows, no serial 64-long chains.
+    float xv[NORM == 2 ? MT : 1][16];
+    float mv2[NORM == 2 ? MT : 1];
+    if (NORM == 2) {
+        if (wave < nch) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int arow = m0 + m * 16 + li;
+                const float* xr = a.A + (size_t)(arow < a.M ? arow : 0) * a.lda + wave * 64 + lg;      // natural layout: k = 4t + g
+                f32x4 sacc = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 16; ++t) xv[m][t] = arow < a.M ? xr[4 * t] : 0.0f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[m][t] * xv[m][t], 1.0f, sacc, 0, 0, 0);
+                if (li == 0) {                               // C/D: row = 4*lg + r (every column holds the same sum)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) nsq[m * 16 + 4 * lg + r][wave] = sacc[r];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float t = nsq[m * 16 + li][0];
+            for (int k = 1; k < nch; ++k) t = t + nsq[m * 16 + li][k];
+            mv2[m] = sqrtf(t / (float)K + a.eps);
+        }
+    }
+    if (NORM == 1) {
         // candle rms_norm: m = sqrt(sum(x*x)/d + eps) with the canonical chunk-64 sum; y = x / m * w   (K <= 1024)
         for (int task = tid; task < MT * 16 * nch; task += blockDim.x) {
             const int r = task / nch, c = task % nch;
@@ -129,31 +167,41 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
         }
         __syncthreads();
     }
-    float tot0[MT], tot1[MT];                    // element (r = tid >> 4, c = tid & 15) of both column tiles of row tile m; threads 0..255
-    float res0[MT], res1[MT];                    // residual, fetched now so that its latency hides under the weight loads + MFMA chain
+    float tot0[NP][MT], tot1[NP][MT];            // element (r = tid >> 4, c = tid & 15) of both column tiles of pair p, row tile m; threads 0..255
+    float res0[NP][MT], res1[NP][MT];            // residual, fetched now so that its latency hides under the weight loads + MFMA chain
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        tot0[m] = 0.0f; tot1[m] = 0.0f; res0[m] = 0.0f; res1[m] = 0.0f;
-        if (EPI == EPI_PLAIN && a.R && tid < 256) {
-            const int row = m0 + m * 16 + (tid >> 4);
-            if (row < a.M) { res0[m] = a.R[(size_t)row * a.ldc + n0 + (tid & 15)]; res1[m] = a.R[(size_t)row * a.ldc + n1 + (tid & 15)]; }
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            tot0[p][m] = 0.0f; tot1[p][m] = 0.0f; res0[p][m] = 0.0f; res1[p][m] = 0.0f;
+            if (EPI == EPI_PLAIN && a.R && tid < 256) {
+                const int row = m0 + m * 16 + (tid >> 4);
+                if (row < a.M) { res0[p][m] = a.R[(size_t)row * a.ldc + n0[p] + (tid & 15)]; res1[p][m] = a.R[(size_t)row * a.ldc + n1[p] + (tid & 15)]; }
+            }
         }
-    }
     for (int c0 = 0; c0 < nch; c0 += NW) {
         const int c = c0 + wave;
-        f32x4 acc0[MT], acc1[MT];
+        f32x4 acc0[NP][MT], acc1[NP][MT];
         if (c < nch) {
-            const uint4* b0p = reinterpret_cast<const uint4*>(a.Wd + (size_t)(n0 + li) * K + c * 64 + lg * 16);
-            const uint4* b1p = reinterpret_cast<const uint4*>(a.Wd + (size_t)(n1 + li) * K + c * 64 + lg * 16);
-            const uint4 b0a = b0p[0], b0b = b0p[1], b1a = b1p[0], b1b = b1p[1];
-            const unsigned w0[8] = {b0a.x, b0a.y, b0a.z, b0a.w, b0b.x, b0b.y, b0b.z, b0b.w};
-            const unsigned w1[8] = {b1a.x, b1a.y, b1a.z, b1a.w, b1b.x, b1b.y, b1b.z, b1b.w};
+            unsigned w0[NP][8], w1[NP][8];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const uint4* b0p = reinterpret_cast<const uint4*>(a.Wd + (size_t)(n0[p] + li) * K + c * 64 + lg * 16);
+                const uint4* b1p = reinterpret_cast<const uint4*>(a.Wd + (size_t)(n1[p] + li) * K + c * 64 + lg * 16);
+                const uint4 b0a = b0p[0], b0b = b0p[1], b1a = b1p[0], b1b = b1p[1];
+                w0[p][0] = b0a.x; w0[p][1] = b0a.y; w0[p][2] = b0a.z; w0[p][3] = b0a.w; w0[p][4] = b0b.x; w0[p][5] = b0b.y; w0[p][6] = b0b.z; w0[p][7] = b0b.w;
+                w1[p][0] = b1a.x; w1[p][1] = b1a.y; w1[p][2] = b1a.z; w1[p][3] = b1a.w; w1[p][4] = b1b.x; w1[p][5] = b1b.y; w1[p][6] = b1b.z; w1[p][7] = b1b.w;
+            }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int arow = m0 + m * 16 + li;
                 f32x4 av[4];
                 if (arow >= a.M) { av[0] = av[1] = av[2] = av[3] = f32x4{0, 0, 0, 0}; }
-                else if (NORM) {
+                else if (NORM == 2) {
+                    const uint16_t* wr = a.normw + c * 64 + lg;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) av[t >> 2][t & 3] = xv[m][t] / mv2[m] * cz_bf16_to_f32(wr[4 * t]);
+                } else if (NORM) {
                     const float* xr = a.A + (size_t)arow * a.lda + c * 64 + lg;        // natural layout: k = 4t + g
                     const uint16_t* wr = a.normw + c * 64 + lg;
                     const float mv = nm[m * 16 + li];
@@ -163,30 +211,35 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
                     const f32x4* ap = reinterpret_cast<const f32x4*>(a.A + (size_t)arow * a.lda + c * 64 + lg * 16);
                     av[0] = ap[0]; av[1] = ap[1]; av[2] = ap[2]; av[3] = ap[3];
                 }
-                f32x4 x0 = f32x4{0, 0, 0, 0}, x1 = f32x4{0, 0, 0, 0};
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const float av_t = av[t >> 2][t & 3];
-                    const float bv0 = (t & 1) ? cz_bits_f32(w0[t >> 1] & 0xffff0000u) : cz_bits_f32(w0[t >> 1] << 16);
-                    const float bv1 = (t & 1) ? cz_bits_f32(w1[t >> 1] & 0xffff0000u) : cz_bits_f32(w1[t >> 1] << 16);
-                    x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av_t, bv0, x0, 0, 0, 0);
-                    x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av_t, bv1, x1, 0, 0, 0);
+                for (int p = 0; p < NP; ++p) {
+                    f32x4 x0 = f32x4{0, 0, 0, 0}, x1 = f32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const float av_t = av[t >> 2][t & 3];
+                        const float bv0 = (t & 1) ? cz_bits_f32(w0[p][t >> 1] & 0xffff0000u) : cz_bits_f32(w0[p][t >> 1] << 16);
+                        const float bv1 = (t & 1) ? cz_bits_f32(w1[p][t >> 1] & 0xffff0000u) : cz_bits_f32(w1[p][t >> 1] << 16);
+                        x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av_t, bv0, x0, 0, 0, 0);
+                        x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av_t, bv1, x1, 0, 0, 0);
+                    }
+                    acc0[p][m] = x0; acc1[p][m] = x1;
                 }
-                acc0[m] = x0; acc1[m] = x1;
             }
         }
         // ordered reduction of the chunk partials, G row tiles per round
 #pragma unroll
         for (int mg = 0; mg < MT; mg += G) {
             if (c < nch) {
-                float* p = part + wave * (G * 2 * 16 * 17);
+                float* pw = part + wave * WSTRIDE;
 #pragma unroll
                 for (int q = 0; q < G; ++q)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {       // C/D: col = li, row = 4*lg + r
-                        p[(q * 2 + 0) * 272 + (4 * lg + r) * 17 + li] = acc0[mg + q][r];
-                        p[(q * 2 + 1) * 272 + (4 * lg + r) * 17 + li] = acc1[mg + q][r];
-                    }
+                    for (int p = 0; p < NP; ++p)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {       // C/D: col = li, row = 4*lg + r
+                            pw[((q * NP + p) * 2 + 0) * 272 + (4 * lg + r) * 17 + li] = acc0[p][mg + q][r];
+                            pw[((q * NP + p) * 2 + 1) * 272 + (4 * lg + r) * 17 + li] = acc1[p][mg + q][r];
+                        }
             }
             __syncthreads();
             if (tid < 256) {
@@ -194,11 +247,13 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
                 const int lim = nch - c0 < NW ? nch - c0 : NW;
 #pragma unroll
                 for (int q = 0; q < G; ++q)
-                    for (int w = 0; w < lim; ++w) {
-                        const float p0 = part[w * (G * 544) + (q * 2 + 0) * 272 + r * 17 + cc];
-                        const float p1 = part[w * (G * 544) + (q * 2 + 1) * 272 + r * 17 + cc];
-                        if (c0 + w == 0) { tot0[mg + q] = p0; tot1[mg + q] = p1; } else { tot0[mg + q] = tot0[mg + q] + p0; tot1[mg + q] = tot1[mg + q] + p1; }
-                    }
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        for (int w = 0; w < lim; ++w) {
+                            const float p0 = part[w * WSTRIDE + ((q * NP + p) * 2 + 0) * 272 + r * 17 + cc];
+                            const float p1 = part[w * WSTRIDE + ((q * NP + p) * 2 + 1) * 272 + r * 17 + cc];
+                            if (c0 + w == 0) { tot0[p][mg + q] = p0; tot1[p][mg + q] = p1; } else { tot0[p][mg + q] = tot0[p][mg + q] + p0; tot1[p][mg + q] = tot1[p][mg + q] + p1; }
+                        }
             }
             __syncthreads();
         }
@@ -206,26 +261,28 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
     if (tid >= 256) return;
     const int r = tid >> 4, cc = tid & 15;
 #pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int row = m0 + m * 16 + r;
         if (row >= a.M) continue;
-        const float t0 = tot0[m], t1 = tot1[m];
+        const float t0 = tot0[p][m], t1 = tot1[p][m];
         if (EPI == EPI_RELUSQ) {                                       // RWKV7 channel-mix key: relu(x)^2, kq layout (feeds the value projection)
             const float z0 = t0 > 0.0f ? t0 : 0.0f, z1 = t1 > 0.0f ? t1 : 0.0f;
-            a.C[(size_t)row * a.ldc + kq_index(n0 + cc)] = z0 * z0;
-            a.C[(size_t)row * a.ldc + kq_index(n1 + cc)] = z1 * z1;
+            a.C[(size_t)row * a.ldc + kq_index(n0[p] + cc)] = z0 * z0;
+            a.C[(size_t)row * a.ldc + kq_index(n1[p] + cc)] = z1 * z1;
         } else if (EPI == EPI_PLAIN) {
             if (a.row_mask && !a.row_mask[row]) continue;
             float v0 = t0, v1 = t1;
-            if (a.R) { v0 = v0 + res0[m]; v1 = v1 + res1[m]; }
-            a.C[(size_t)row * a.ldc + n0 + cc] = v0;
-            a.C[(size_t)row * a.ldc + n1 + cc] = v1;
+            if (a.R) { v0 = v0 + res0[p][m]; v1 = v1 + res1[p][m]; }
+            a.C[(size_t)row * a.ldc + n0[p] + cc] = v0;
+            a.C[(size_t)row * a.ldc + n1[p] + cc] = v1;
         } else if (EPI == EPI_SWIGLU) {
-            a.C[(size_t)row * a.ldc + kq_index(n0 + cc)] = cz_siluf(t0) * t1;      // silu(gate) * up  (llama.rs MLP)
+            a.C[(size_t)row * a.ldc + kq_index(n0[p] + cc)] = cz_siluf(t0) * t1;      // silu(gate) * up  (llama.rs MLP)
         } else {
             cz_rope_desc d = a.descs[row];           // one row per stream
             const int pos = a.pos_dev ? *a.pos_dev : d.pos0;
-            const int head = n0 >> 6, i = (n0 & 63) + cc;                             // rotation index i in [0, 32)
+            const int head = n0[p] >> 6, i = (n0[p] & 63) + cc;                       // rotation index i in [0, 32)
             if (head < a.n_heads + a.n_kv) {
                 const float c_ = a.cs[(size_t)pos * 32 + i], s_ = a.sn[(size_t)pos * 32 + i];
                 const float aa = t0 * c_, bb = t1 * s_, c2 = t0 * s_, dd = t1 * c_;      // candle rope: products rounded separately
@@ -247,8 +304,8 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
     }
 }
 
-template <int EPI, int NORM, int MT>
-__global__ __launch_bounds__(768) void dec_gemm_kernel(dec_gemm_args a) { dec_gemm_body<EPI, NORM, MT>(a, blockIdx.x, blockIdx.y); }
+template <int EPI, int NORM, int MT, int NP>
+__global__ __launch_bounds__(768) void dec_gemm_kernel(dec_gemm_args a) { dec_gemm_body<EPI, NORM, MT, NP>(a, blockIdx.x, blockIdx.y); }
 
 // Several independent plain GEMMs of one decode step in ONE launch (blockIdx.z = problem): the RWKV7 time-mix needs seven
 // projections of differently mixed inputs, then four LoRA up-projections; as separate launches they cost ~7 us each for a few
@@ -259,17 +316,26 @@ template <int MT>
 __global__ __launch_bounds__(768) void dec_gemm_group_kernel(dec_gemm_group g) {
     const int z = blockIdx.z;
     if ((int)blockIdx.x >= g.gx[z]) return;
-    dec_gemm_body<EPI_PLAIN, 0, MT>(g.a[z], blockIdx.x, blockIdx.y);
+    dec_gemm_body<EPI_PLAIN, 0, MT, 1>(g.a[z], blockIdx.x, blockIdx.y);
 }
 
 int g_dec_nw_cap = 12;           // tuning knob (cz_debug_set "dec_nw_cap"): waves per decode-GEMM block (each wave owns K chunks round-robin)
 static int dec_nw(int K) { int nch = K / 64; nch = nch < g_dec_nw_cap ? nch : g_dec_nw_cap; return nch < 4 ? 4 : nch; }   // >= 256 threads: one per element of a tile
-template <int EPI, int NORM, int MT>
+template <int EPI, int NORM, int MT, int NP = 1>
 static hipError_t dec_gemm_launch_mt(hipStream_t st, const dec_gemm_args& a, int gx) {
     const int NW = dec_nw(a.K);
     const int G = MT < 2 ? MT : 2;
-    const size_t smem = (size_t)NW * G * 2 * 16 * 17 * sizeof(float);
-    hipLaunchKernelGGL((dec_gemm_kernel<EPI, NORM, MT>), dim3(gx, (a.M + MT * 16 - 1) / (MT * 16)), dim3(64 * NW), smem, st, a);
+    const size_t smem = (size_t)NW * G * NP * 2 * 16 * 17 * sizeof(float);
+    auto kern = dec_gemm_kernel<EPI, NORM, MT, NP>;
+    if (smem > 48 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 2 * NP * 2 * 16 * 17 * (int)sizeof(float));
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(gx / NP, (a.M + MT * 16 - 1) / (MT * 16)), dim3(64 * NW), smem, st, a);
     return hipGetLastError();
 }
 int g_dec_grid_target = 384;     // tuning knob (cz_debug_set "dec_grid_target")
@@ -287,10 +353,23 @@ static hipError_t dec_gemm_launch_n(hipStream_t st, const dec_gemm_args& a, int 
         default: return dec_gemm_launch_mt<EPI, NORM, 8>(st, a, gx);
     }
 }
+int g_dec_norm_mfma = 1;         // tuning knob (cz_debug_set "dec_norm_mfma"): 0 = the separate sum-of-squares pass (NORM = 1) everywhere
+int g_dec_wide_rows = 256;       // tuning knob (cz_debug_set "dec_wide_rows"): from this many rows on, blocks of 32 rows x 64 columns (MT = 2, NP = 2)
 template <int EPI>
 static hipError_t dec_gemm_launch(hipStream_t st, const dec_gemm_args& a, int gx) {
+    if (a.M >= g_dec_wide_rows && gx % 2 == 0) {
+        if (!a.normw) return dec_gemm_launch_mt<EPI, 0, 2, 2>(st, a, gx);
+        if (a.K > 1024) return hipErrorInvalidValue;
+        if (g_dec_norm_mfma && a.K / 64 <= dec_nw(a.K)) return dec_gemm_launch_mt<EPI, 2, 2, 2>(st, a, gx);
+        return dec_gemm_launch_mt<EPI, 1, 2, 2>(st, a, gx);
+    }
     if (a.normw) {
         if (a.K > 1024) return hipErrorInvalidValue;
+        if (g_dec_norm_mfma && a.K / 64 <= dec_nw(a.K)) {       // one round of chunks: the fused MFMA sum of squares (at most two row tiles per block)
+            const int mt_all = (a.M + 15) / 16;
+            if (mt_all >= 2 && (long)gx * mt_all > g_dec_grid_target) return dec_gemm_launch_mt<EPI, 2, 2>(st, a, gx);
+            return dec_gemm_launch_mt<EPI, 2, 1>(st, a, gx);
+        }
         return dec_gemm_launch_n<EPI, 1>(st, a, gx);
     }
     return dec_gemm_launch_n<EPI, 0>(st, a, gx);
@@ -346,6 +425,9 @@ hipError_t cz_launch_dec_gemm_qkv(hipStream_t st, const float* A, int lda, const
     a.n_heads = n_heads; a.n_kv = n_kv; a.descs = descs; a.kv_off = kv_off; a.pos_dev = pos_dev; a.cs = cs; a.sn = sn;
     return dec_gemm_launch<EPI_ROPE>(st, a, (n_heads + 2 * n_kv) * 2);
 }
+// true when a norm-fused projection of K inputs takes the single-round MFMA sum-of-squares path (otherwise every column block would
+// repeat a pass over its rows, and wide projections normalise once with dec_rmsnorm_kernel instead)
+bool cz_dec_gemm_norm_is_cheap(int K) { return g_dec_norm_mfma && K % 64 == 0 && K <= 1024 && K / 64 <= dec_nw(K); }
 // fused gate|up projection + SwiGLU; H [M][f] in kq layout
 hipError_t cz_launch_dec_gemm_swiglu(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* H, int ldh, int M, int f, int K,
                                      const uint16_t* normw, float eps) {
@@ -369,7 +451,7 @@ typedef __attribute__((address_space(1))) const float gfloat;     // K/V pointer
 template <int rep>   // query heads per kv head: compile-time so that the per-head code carries no branches
 __global__ __launch_bounds__(DA_THREADS, 4) void dec_attn_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
                                                               const cz_seq_desc* __restrict__ descs, int n_heads, int n_kv, int s_stride,
-                                                              size_t kv_off, const int* __restrict__ pos_dev) {
+                                                              size_t kv_off, const int* __restrict__ pos_dev, int out_kq) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     cz_seq_desc sd = descs[blockIdx.x];
     const int pos = pos_dev ? *pos_dev : sd.pos0;
@@ -525,7 +607,8 @@ __global__ __launch_bounds__(DA_THREADS, 4) void dec_attn_kernel(const float* __
         const int h = tid >> 6, dd = tid & 63;
         float t = part[(0 * DA_MAXREP + h) * 64 + dd];
         for (int c = 1; c < nch; ++c) t = t + part[(c * DA_MAXREP + h) * 64 + dd];
-        O[(size_t)sd.row0 * ldo + kq_index((kvh * rep + h) * 64 + dd)] = t;      // kq layout: feeds the o-projection
+        const int col = (kvh * rep + h) * 64 + dd;
+        O[(size_t)sd.row0 * ldo + (out_kq ? kq_index(col) : col)] = t;          // kq layout feeds dec_gemm_kernel's o-projection, natural layout the tiled GEMM
     }
 }
 static int da_s_stride(int max_nk) { return ((max_nk + 63) / 64) * 64 + 4; }
@@ -540,17 +623,17 @@ hipError_t cz_dec_attn_prepare(int max_nk) {
     return e;
 }
 hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nstreams, int max_nk,
-                              int n_heads, int n_kv, size_t kv_off, const int* pos_dev) {
+                              int n_heads, int n_kv, size_t kv_off, const int* pos_dev, int out_kq) {
     if (nstreams <= 0) return hipSuccess;
     const int rep = n_heads / n_kv;
     if (rep < 1 || rep > DA_MAXREP || max_nk > 2048) return hipErrorInvalidValue;
     const dim3 grid(nstreams, n_kv), block(DA_THREADS);
     const size_t smem = da_smem(max_nk); const int ss = da_s_stride(max_nk);
     switch (rep) {
-        case 1: hipLaunchKernelGGL(dec_attn_kernel<1>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev); break;
-        case 2: hipLaunchKernelGGL(dec_attn_kernel<2>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev); break;
-        case 3: hipLaunchKernelGGL(dec_attn_kernel<3>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev); break;
-        default: hipLaunchKernelGGL(dec_attn_kernel<4>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev); break;
+        case 1: hipLaunchKernelGGL(dec_attn_kernel<1>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;
+        case 2: hipLaunchKernelGGL(dec_attn_kernel<2>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;
+        case 3: hipLaunchKernelGGL(dec_attn_kernel<3>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;
+        default: hipLaunchKernelGGL(dec_attn_kernel<4>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;
     }
     return hipGetLastError();
 }

@@ -255,9 +255,13 @@ hipError_t cz_launch_gu_interleave(hipStream_t st, const uint16_t* W, uint16_t* 
     return hipGetLastError();
 }
 // H[M][f] = silu(A . Wgate^T) * (A . Wup^T) with Wi from cz_launch_gu_interleave (big-M path only)
+// mid-M (one wide lock-step decode group, a few hundred rows): 64-row tiles, so that a projection of a few hundred rows still spreads
+// over most of the 256 CUs (a 128-row tile would leave M / 128 x N / 64 = a few dozen blocks)
+int g_gemm_mid_rows = 2048;      // tuning knob (cz_debug_set "gemm_mid_rows"): M <= this uses the 64-row tiles
 hipError_t cz_launch_gemm_swiglu(hipStream_t st, const float* A, int lda, const uint16_t* Wi, float* H, int ldh, int M, int f, int K) {
     if (M <= 0) return hipSuccess;
     if (K % 64 != 0 || (2 * f) % 128 != 0) return hipErrorInvalidValue;
+    if (M <= g_gemm_mid_rows) return launch_big<64, 128, 2, 2, 1>(st, A, lda, Wi, H, ldh, nullptr, 0, M, 2 * f, K);
     return launch_big<128, 128, 2, 2, 1>(st, A, lda, Wi, H, ldh, nullptr, 0, M, 2 * f, K);
 }
 
@@ -277,6 +281,7 @@ hipError_t cz_launch_gemm(hipStream_t st, const float* A, int lda, const uint16_
         return hipGetLastError();
     }
     if (N % 64 != 0) return hipErrorInvalidValue;
+    if (M <= g_gemm_mid_rows && (long)((M + 127) / 128) * (N / 64) < 512) return launch_big<64, 64, 2, 2>(st, A, lda, W, C, ldc, R, ldr, M, N, K);
     if (N % 128 == 0) return launch_big<128, 128, 2, 2>(st, A, lda, W, C, ldc, R, ldr, M, N, K);
     return launch_big<128, 64, 2, 2>(st, A, lda, W, C, ldc, R, ldr, M, N, K);
 }

@@ -27,6 +27,9 @@ extern int g_attn_v1;
 extern int g_dec_grid_target;
 extern int g_dec_nw_cap;
 extern int g_dec_mt_max;
+extern int g_dec_norm_mfma;
+extern int g_gemm_mid_rows;
+extern int g_dec_wide_rows;
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t _e = (expr);                                                                        \
@@ -375,9 +378,12 @@ static cz_status llama_step_fast(cz_session* s, int B, int pos, int max_nk) {
         }
         if (s->dbg_skip & 2) continue;
         s->prof_begin(PK_DEC_GEMM); HIPCHK(cz_launch_dec_gemm_plain(st, att, d, dec(y.wo), x, d, x, B, d, d, nullptr, 0.0f)); s->prof_end(2.0 * B * (double)d * d, (double)d * d * 2);
-        // wide projections (gate|up, lm_head) have many column blocks: normalise once instead of once per block
-        s->prof_begin(PK_DEC_NORM); HIPCHK(cz_launch_dec_rmsnorm(st, x, d, y.ln2, xn, d, B, d, c.rms_eps)); s->prof_end(0, (double)B * d * 8);
-        s->prof_begin(PK_DEC_GEMM_GU); HIPCHK(cz_launch_dec_gemm_swiglu(st, xn, d, dec(y.wgu), h, f, B, f, d, nullptr, 0.0f)); s->prof_end(4.0 * B * (double)f * d, (double)f * d * 4);
+        if (s->fuse_norm && cz_dec_gemm_norm_is_cheap(d)) {       // RMSNorm(ln2) inside the gate|up projection: sum of squares on the MFMA, x read once per block
+            s->prof_begin(PK_DEC_GEMM_GU); HIPCHK(cz_launch_dec_gemm_swiglu(st, x, d, dec(y.wgu), h, f, B, f, d, y.ln2, c.rms_eps)); s->prof_end(4.0 * B * (double)f * d, (double)f * d * 4);
+        } else {                                                   // many column blocks would each repeat a pass over their rows: normalise once
+            s->prof_begin(PK_DEC_NORM); HIPCHK(cz_launch_dec_rmsnorm(st, x, d, y.ln2, xn, d, B, d, c.rms_eps)); s->prof_end(0, (double)B * d * 8);
+            s->prof_begin(PK_DEC_GEMM_GU); HIPCHK(cz_launch_dec_gemm_swiglu(st, xn, d, dec(y.wgu), h, f, B, f, d, nullptr, 0.0f)); s->prof_end(4.0 * B * (double)f * d, (double)f * d * 4);
+        }
         s->prof_begin(PK_DEC_GEMM); HIPCHK(cz_launch_dec_gemm_plain(st, h, f, dec(y.wd), x, d, x, B, d, f, nullptr, 0.0f)); s->prof_end(2.0 * B * (double)d * f, (double)d * f * 2);
     }
     s->prof_begin(PK_DEC_NORM); HIPCHK(cz_launch_dec_rmsnorm(st, x, d, m.lnf, xn, d, B, d, c.rms_eps)); s->prof_end(0, (double)B * d * 8);
@@ -386,11 +392,65 @@ static cz_status llama_step_fast(cz_session* s, int B, int pos, int max_nk) {
     s->prof_end(2.0 * B * (double)c.vocab * d, (double)c.vocab * d * 2 + (double)B * c.vocab * 4);
     return CZ_OK;
 }
+// The same step for ONE WIDE lock-step group (a few hundred to 1024 streams): the projections go through the LDS-tiled MFMA GEMM with
+// 64-row tiles instead of the latency-oriented dec_gemm_kernel (whose blocks re-read the activations once per 32 output columns and
+// reach 10-30 % of the MFMA rate at these row counts); attention is the same dec_attn_kernel (natural-layout output), HBM-bound on the
+// KV cache and, with B x n_kv >> 256 blocks, evenly spread over the CUs.  Same canonical arithmetic, same bits.
+static cz_status llama_step_wide(cz_session* s, int B, int pos, int max_nk) {
+    const LlamaModel& m = s->llama; const cz_llama_config& c = m.cfg;
+    const int d = c.d_model, f = c.d_ffn, kvd = c.n_kv_heads * 64, nq = d + 2 * kvd;
+    CZCHK(s->x.ensure((size_t)B * d * 4)); CZCHK(s->xn.ensure((size_t)B * d * 4)); CZCHK(s->qkv.ensure((size_t)B * nq * 4)); CZCHK(s->h.ensure((size_t)B * f * 4));
+    const bool fused_gu = m.L[0].wgu_i != nullptr;
+    if (!fused_gu) CZCHK(s->gu.ensure((size_t)B * 2 * f * 4));
+    float *x = (float*)s->x.p, *xn = (float*)s->xn.p, *qkv = (float*)s->qkv.p, *gu = (float*)s->gu.p, *h = (float*)s->h.p;
+    hipStream_t st = s->stream;
+    auto gemm = [&](int kind, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R, int N, int K) -> hipError_t {
+        s->prof_begin(kind);
+        hipError_t e = cz_launch_gemm(st, A, lda, W, C, ldc, R, ldc, B, N, K, 1);
+        s->prof_end(2.0 * B * (double)N * K, (double)N * K * 2 + (double)B * (N + K) * 4);
+        return e;
+    };
+    s->prof_begin(PK_EMBED); HIPCHK(cz_launch_embed(st, (const uint32_t*)s->tok.p, m.E, x, B, d)); s->prof_end(0, (double)B * d * 6);
+    for (int l = 0; l < c.n_layers; ++l) {
+        const LlamaModel::Layer& y = m.L[l];
+        const size_t kv_off = (size_t)l * s->kv_layer_stride;
+        if (!(s->dbg_skip & 2)) {
+            s->prof_begin(PK_DEC_NORM); HIPCHK(cz_launch_rmsnorm(st, x, d, y.ln1, xn, d, B, d, c.rms_eps, nullptr)); s->prof_end(0, (double)B * d * 8);
+            HIPCHK(gemm(PK_DEC_GEMM_QKV, xn, d, y.wqkv, qkv, nq, nullptr, nq, d));
+            s->prof_begin(PK_ROPE);                                                        // q rotated in place; k (rotated) and v go to the cache rows at *pos_dev
+            HIPCHK(cz_launch_rope(st, qkv, nq, s->step_roped, B, 1, c.n_heads, c.n_kv_heads, m.rope_cos, m.rope_sin, kv_off, s->pos_dev));
+            s->prof_end(0, (double)B * nq * 8);
+        }
+        if (!(s->dbg_skip & 1)) {
+            s->prof_begin(PK_DEC_ATTN);
+            HIPCHK(cz_launch_dec_attn(st, qkv, nq, xn, d, s->step_seqd, B, max_nk, c.n_heads, c.n_kv_heads, kv_off, s->pos_dev, 0));
+            s->prof_end(4.0 * 64 * c.n_heads * (double)B * (pos + 1), 2.0 * B * (double)(pos + 1) * kvd * 4);
+        }
+        if (s->dbg_skip & 2) continue;
+        HIPCHK(gemm(PK_DEC_GEMM, xn, d, y.wo, x, d, x, d, d));                              // x = attn_out . Wo^T + x
+        s->prof_begin(PK_DEC_NORM); HIPCHK(cz_launch_rmsnorm(st, x, d, y.ln2, xn, d, B, d, c.rms_eps, nullptr)); s->prof_end(0, (double)B * d * 8);
+        if (fused_gu) {
+            s->prof_begin(PK_DEC_GEMM_GU); HIPCHK(cz_launch_gemm_swiglu(st, xn, d, y.wgu_i, h, f, B, f, d)); s->prof_end(4.0 * B * (double)f * d, (double)f * d * 4);
+        } else {
+            HIPCHK(gemm(PK_DEC_GEMM_GU, xn, d, y.wgu, gu, 2 * f, nullptr, 2 * f, d));
+            s->prof_begin(PK_SWIGLU); HIPCHK(cz_launch_swiglu(st, gu, h, B, f)); s->prof_end(0, (double)B * f * 12);
+        }
+        HIPCHK(gemm(PK_DEC_GEMM, h, f, y.wd, x, d, x, d, f));                               // x = mlp_out + x
+    }
+    s->prof_begin(PK_DEC_NORM); HIPCHK(cz_launch_rmsnorm(st, x, d, m.lnf, xn, d, B, d, c.rms_eps, nullptr)); s->prof_end(0, (double)B * d * 8);
+    HIPCHK(gemm(PK_DEC_GEMM_HEAD, xn, d, m.E, s->step_logits, c.vocab, nullptr, c.vocab, d));
+    return CZ_OK;
+}
+// the lock-step decode step: the latency-oriented kernels for narrow groups, the tiled-GEMM chain for wide ones
+static cz_status llama_step_any(cz_session* s, int B, int pos, int max_nk) {
+    if (s->wide_min_streams > 0 && B >= s->wide_min_streams) return llama_step_wide(s, B, pos, max_nk);
+    return llama_step_fast(s, B, pos, max_nk);
+}
 // one token per stream at position `pos` (tokens in s->tok[0..B)); logits -> s->step_logits [B][V]
 static cz_status llama_step(cz_session* s, int B, int pos) {
     if (pos >= CZ_MAX_CTX || pos >= s->llama.cfg.max_pos || (s->ctx_cap && pos >= (int)s->ctx_cap)) { cz_set_error("position %d exceeds the supported context (%d)", pos, CZ_MAX_CTX); return CZ_ERR_STATE; }
     hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, pos);
-    if (!s->decode_v1 && s->llama.cfg.n_heads / s->llama.cfg.n_kv_heads <= 4) return llama_step_fast(s, B, pos, pos + 1);
+    if (!s->decode_v1 && s->llama.cfg.n_heads / s->llama.cfg.n_kv_heads <= 4) return llama_step_any(s, B, pos, pos + 1);
     if (B > 64) s->force_big_gemm = 1;                     // the general skinny kernel covers M <= 64 only
     CZCHK(llama_body(s, B, s->step_seqd, s->step_roped, B, 1, pos + 1, s->kv_layer_stride, s->pos_dev));
     return llama_head(s, s->step_rows, B, s->step_logits);
@@ -442,13 +502,13 @@ static cz_status build_step_graph(cz_session* s, int B) {
     const unsigned long long* step_dev = reinterpret_cast<const unsigned long long*>(s->pos_dev + 2);
     const bool prof = s->prof_on; s->prof_on = false;            // no events inside a captured region
     // every buffer the captured kernels touch must exist before capture starts
-    cz_status rc = llama_step_fast(s, B, 0, CZ_MAX_CTX);
+    cz_status rc = llama_step_any(s, B, 0, CZ_MAX_CTX);
     if (rc != CZ_OK) { s->prof_on = prof; return rc; }
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
     hipError_t e = cz_launch_decode_symbol(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, 0ull, s->fallback_dev, step_dev, s->cdf_scratch);
     if (e == hipSuccess) e = hipMemcpyAsync(s->tok.p, s->step_sym, (size_t)B * 4, hipMemcpyDeviceToDevice, s->stream);
-    if (e == hipSuccess) rc = llama_step_fast(s, B, 0, CZ_MAX_CTX);
+    if (e == hipSuccess) rc = llama_step_any(s, B, 0, CZ_MAX_CTX);
     if (e == hipSuccess && rc == CZ_OK) { hipLaunchKernelGGL(inc_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev); e = hipGetLastError(); }
     hipGraph_t g = nullptr;
     hipError_t e2 = hipStreamEndCapture(s->stream, &g);
@@ -795,7 +855,7 @@ extern "C" cz_status cz_session_open(const cz_model_desc* desc, int device_ordin
     cz_session* s = new cz_session();
     s->backend = desc->backend; s->device = device_ordinal; s->seed = desc->synthetic_seed; s->round_f32 = desc->round_f32_weights_to_bf16 != 0;
     s->max_streams = desc->max_streams ? (int)desc->max_streams : 64;
-    if (s->max_streams > 256) { delete s; cz_set_error("max_streams > 256 is not supported"); return CZ_ERR_ARG; }
+    if (s->max_streams > CZ_CDF_PAR_MAX_GRID) { delete s; cz_set_error("max_streams > %d is not supported", CZ_CDF_PAR_MAX_GRID); return CZ_ERR_ARG; }
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);   // several sessions may capture/replay graphs concurrently
     if (e != hipSuccess) { delete s; cz_set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return CZ_ERR_HIP; }
     if (hipMalloc((void**)&s->fallback_dev, 64) != hipSuccess || hipMemset(s->fallback_dev, 0, 64) != hipSuccess) { delete s; cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
@@ -827,6 +887,8 @@ extern "C" void cz_session_close(cz_session* s) {
     if (s->is_lane) { s->llama.blob = s->llama.blob_dec = s->llama.blob_gu = nullptr; s->llama.rope_cos = s->llama.rope_sin = nullptr; }   // the weights belong to the parent
     if (s->stream) hipStreamSynchronize(s->stream);
     destroy_step_graph(s);
+    if (s->dbg_ge) hipGraphExecDestroy(s->dbg_ge);
+    if (s->dbg_g) hipGraphDestroy(s->dbg_g);
     s->prof_drain();
     for (auto e : s->evt_free) hipEventDestroy(e);
     DevBuf* bufs[] = {&s->tok, &s->x, &s->xn, &s->qkv, &s->gu, &s->h, &s->seqd, &s->roped, &s->rowidx, &s->sym, &s->clo, &s->chi, &s->xl,
@@ -896,7 +958,7 @@ static cz_status make_lane(cz_session* p, cz_session** out) {
 }
 static void lane_inherit(const cz_session* s, cz_session* ls) {   // a lane runs with its parent's knobs
     ls->kv_ctx_cap = s->kv_ctx_cap; ls->serial_cdf = s->serial_cdf; ls->decode_v1 = s->decode_v1; ls->no_graph = s->no_graph; ls->force_big_gemm = s->force_big_gemm;
-    ls->max_batch_rows = s->max_batch_rows; ls->logit_batch_rows = s->logit_batch_rows; ls->step_sync = s->step_sync; ls->fuse_norm = s->fuse_norm;
+    ls->max_batch_rows = s->max_batch_rows; ls->logit_batch_rows = s->logit_batch_rows; ls->step_sync = s->step_sync; ls->fuse_norm = s->fuse_norm; ls->wide_min_streams = s->wide_min_streams; ls->dbg_skip = s->dbg_skip;
 }
 // run `n_streams` streams as groups of <= max_streams on up to max_lanes lanes; group(ls, off, count) processes streams [off, off + count)
 template <class GroupFn>
@@ -1103,55 +1165,61 @@ extern "C" cz_status cz_synchronize(cz_session* s) {
     HIPCHK(hipStreamSynchronize(s->stream));
     return CZ_OK;
 }
-// tuning aid (tools/bench_decode_step.py): `iters` lock-step decode steps of B streams at a FIXED position `pos` (KV cache zeroed), as a
-// replayed hipGraph (use_graph) or eagerly (per-family HIP events when profiling is on).  *ms_total = device time of the iters steps.
+// tuning aid (tools/bench_decode_step.py): lock-step decode steps of B streams at a FIXED position `pos` (KV cache zeroed), as a replayed
+// hipGraph (use_graph) or eagerly (per-family HIP events when profiling is on).  iters <= 0 prepares (buffers, graph capture, one warm
+// step) so that several lanes can start their timed loops together; iters > 0 runs the loop: *ms_total = device time of the iters steps.
 extern "C" cz_status cz_debug_decode_steps(cz_session* s, int B, int pos, int iters, int use_graph, int with_symbol, double* ms_total) {
-    if (!s || !ms_total || s->backend != CZ_BACKEND_SMOLLM || B <= 0 || iters <= 0) { cz_set_error("cz_debug_decode_steps: bad argument"); return CZ_ERR_ARG; }
+    if (!s || !ms_total || s->backend != CZ_BACKEND_SMOLLM || B <= 0) { cz_set_error("cz_debug_decode_steps: bad argument"); return CZ_ERR_ARG; }
     HIPCHK(hipSetDevice(s->device));
     const cz_llama_config& c = s->llama.cfg;
-    CZCHK(ensure_streams(s, B));
-    if (pos < 0 || pos >= (int)s->ctx_cap) { cz_set_error("pos out of range"); return CZ_ERR_ARG; }
-    CZCHK(s->tok.ensure((size_t)B * 4)); CZCHK(s->decst.ensure(B * sizeof(cz_dec_state))); CZCHK(s->payload.ensure((size_t)B * 64)); CZCHK(s->outids.ensure((size_t)B * 16));
-    HIPCHK(hipMemsetAsync(s->kvcache, 0, (size_t)s->max_streams * s->kv_stream_stride * 4, s->stream));
-    HIPCHK(hipMemsetAsync(s->payload.p, 0x5a, (size_t)B * 64, s->stream));
-    std::vector<cz_dec_state> hs(B);
-    for (int b = 0; b < B; ++b) {
-        cz_dec_state d; memset(&d, 0, sizeof d);
-        d.in = (const uint8_t*)s->payload.p + (size_t)b * 64; d.in_len = 64; d.out_ids = (uint32_t*)s->outids.p + (size_t)b * 4; d.token_count = 0; d.active = 0;   // inactive: state is read, nothing is written
-        hs[b] = d;
-    }
-    HIPCHK(hipMemcpyAsync(s->decst.p, hs.data(), B * sizeof(cz_dec_state), hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
-    hipLaunchKernelGGL(fill_u32_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, (uint32_t*)s->tok.p, 1u, B);
-    hipLaunchKernelGGL(set_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, pos, 0ull);
     auto one = [&]() -> cz_status {
         if (with_symbol) HIPCHK(cz_launch_decode_symbol(s->stream, s->step_logits, c.vocab, (cz_dec_state*)s->decst.p, s->step_sym, B, c.vocab, 0, 0ull, s->fallback_dev, nullptr, s->cdf_scratch));
-        return llama_step_fast(s, B, pos, use_graph ? CZ_MAX_CTX : pos + 1);
+        return llama_step_any(s, B, pos, use_graph ? CZ_MAX_CTX : pos + 1);
     };
-    CZCHK(one());                                                   // sizes every buffer, pages the code in
-    HIPCHK(hipStreamSynchronize(s->stream));
-    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
-    if (use_graph) {
-        const bool prof = s->prof_on; s->prof_on = false;
-        HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-        const cz_status rc = one();
-        const hipError_t e2 = hipStreamEndCapture(s->stream, &g);
-        s->prof_on = prof;
-        if (rc != CZ_OK || e2 != hipSuccess || !g) { cz_set_error("capture failed"); return CZ_ERR_HIP; }
-        HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        HIPCHK(hipGraphLaunch(ge, s->stream));
+    if (iters <= 0) {
+        CZCHK(ensure_streams(s, B));
+        if (pos < 0 || pos >= (int)s->ctx_cap) { cz_set_error("pos out of range"); return CZ_ERR_ARG; }
+        CZCHK(s->tok.ensure((size_t)B * 4)); CZCHK(s->decst.ensure(B * sizeof(cz_dec_state))); CZCHK(s->payload.ensure((size_t)B * 64)); CZCHK(s->outids.ensure((size_t)B * 16));
+        HIPCHK(hipMemsetAsync(s->kvcache, 0, (size_t)s->max_streams * s->kv_stream_stride * 4, s->stream));
+        HIPCHK(hipMemsetAsync(s->payload.p, 0x5a, (size_t)B * 64, s->stream));
+        std::vector<cz_dec_state> hs(B);
+        for (int b = 0; b < B; ++b) {
+            cz_dec_state d; memset(&d, 0, sizeof d);
+            d.in = (const uint8_t*)s->payload.p + (size_t)b * 64; d.in_len = 64; d.out_ids = (uint32_t*)s->outids.p + (size_t)b * 4; d.token_count = 1u << 30; d.active = 1;
+            hs[b] = d;
+        }
+        HIPCHK(hipMemcpyAsync(s->decst.p, hs.data(), B * sizeof(cz_dec_state), hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
+        HIPCHK(cz_launch_dec_init(s->stream, (cz_dec_state*)s->decst.p, B));
+        hipLaunchKernelGGL(fill_u32_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, (uint32_t*)s->tok.p, 1u, B);
+        hipLaunchKernelGGL(set_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, pos, 0ull);    // the symbol kernel writes out_ids[1] every step (step index 0)
+        CZCHK(one());                                                   // sizes every buffer, pages the code in
+        HIPCHK(hipStreamSynchronize(s->stream));
+        if (s->dbg_ge) { hipGraphExecDestroy(s->dbg_ge); s->dbg_ge = nullptr; }
+        if (s->dbg_g) { hipGraphDestroy(s->dbg_g); s->dbg_g = nullptr; }
+        if (use_graph) {
+            const bool prof = s->prof_on; s->prof_on = false;
+            HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+            const cz_status rc = one();
+            const hipError_t e2 = hipStreamEndCapture(s->stream, &s->dbg_g);
+            s->prof_on = prof;
+            if (rc != CZ_OK || e2 != hipSuccess || !s->dbg_g) { cz_set_error("capture failed"); return CZ_ERR_HIP; }
+            HIPCHK(hipGraphInstantiate(&s->dbg_ge, s->dbg_g, nullptr, nullptr, 0));
+            HIPCHK(hipGraphLaunch(s->dbg_ge, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+        }
+        *ms_total = 0.0;
+        return CZ_OK;
     }
+    if (use_graph && !s->dbg_ge) { cz_set_error("cz_debug_decode_steps: prepare first (iters <= 0)"); return CZ_ERR_STATE; }
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, s->stream));
-    for (int i = 0; i < iters; ++i) { if (use_graph) HIPCHK(hipGraphLaunch(ge, s->stream)); else CZCHK(one()); }
+    for (int i = 0; i < iters; ++i) { if (use_graph) HIPCHK(hipGraphLaunch(s->dbg_ge, s->stream)); else CZCHK(one()); }
     HIPCHK(hipEventRecord(e1, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     *ms_total = ms;
     hipEventDestroy(e0); hipEventDestroy(e1);
-    if (ge) hipGraphExecDestroy(ge);
-    if (g) hipGraphDestroy(g);
     return CZ_OK;
 }
 // restrict this session's stream to the CUs of one XCD (experiment: lanes that do not share an L2).  CU-mask bit i belongs to XCD i % 8.
@@ -1184,8 +1252,12 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "probe_launch")) s->probe_launch = (int)value;
     else if (!strcmp(key, "cu_mask_xcd")) return set_stream_xcd(s, (int)(value % 16), (int)(value / 16) + 1);   // value = first_xcd + 16 * (n_xcd - 1); -1: no mask
     else if (!strcmp(key, "step_sync")) s->step_sync = (int)value;
+    else if (!strcmp(key, "wide_min_streams")) s->wide_min_streams = (int)value;
+    else if (!strcmp(key, "gemm_mid_rows")) g_gemm_mid_rows = (int)value;
+    else if (!strcmp(key, "dec_wide_rows")) g_dec_wide_rows = (int)value;
     else if (!strcmp(key, "dbg_skip")) s->dbg_skip = (int)value;          // tools/bench_decode_step.py: 1 = no attention, 2 = no GEMMs/norms (timing only; results are garbage)
     else if (!strcmp(key, "fuse_norm")) s->fuse_norm = (int)value;
+    else if (!strcmp(key, "dec_norm_mfma")) g_dec_norm_mfma = (int)value;
     else if (!strcmp(key, "dec_grid_target")) g_dec_grid_target = (int)value;
     else if (!strcmp(key, "dec_mt_max")) g_dec_mt_max = (int)value >= 8 ? 8 : ((int)value >= 4 ? 4 : ((int)value >= 2 ? 2 : 1));
     else if (!strcmp(key, "dec_nw_cap")) g_dec_nw_cap = (int)value < 4 ? 4 : ((int)value > 12 ? 12 : (int)value);

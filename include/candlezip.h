@@ -53,7 +53,7 @@ typedef struct cz_model_desc {
     float synthetic_embed_std;
     cz_llama_config llama;
     cz_rwkv7_config rwkv;
-    uint32_t max_streams;               /* capacity of the lock-step decode batch (0 => 64, at most 256) */
+    uint32_t max_streams;               /* capacity of one lock-step decode group (0 => 64, at most 1024); KV cache: 94 MB per stream at the SmolLM2-135M shape */
     /* Weights live in HBM as bf16.  An F32 tensor whose values bf16 cannot hold (the converted RWKV7 checkpoints) is refused
      * (CZ_ERR_UNSUPPORTED) unless this is non-zero: then it is rounded to nearest-even bf16 — a slightly different model than the
      * reference's f32 one (other payloads, still self-consistent between compress and decompress).  Explicit opt-in only. */

@@ -161,3 +161,51 @@ def test_corpus_driver_rwkv7_backend(golden):
     d = _corpus("--backend", "rwkv7", "--synthetic", "5", "--rwkv-tokenizer", os.path.join(golden, "world_vocab_test.json"), "--chunk-bytes", "16384",
                 "--max-streams", "16", *files)
     assert d["backend"] == "rwkv7" and d["roundtrip_failures"] == [] and d["chunks"] == 1 + 8 and d["lossy_utf8_chunks"] == 0 and d["tokens"] > 70000
+
+
+def _eq(a, b, what):
+    a = np.ascontiguousarray(a, np.float32).view(np.uint32); b = np.ascontiguousarray(b, np.float32).view(np.uint32)
+    n = int(np.sum(a != b))
+    assert n == 0, f"{what}: {n}/{a.size} logits differ"
+
+
+@pytest.mark.parametrize("path", ["tiled", "np2"])
+@pytest.mark.parametrize("shape", ["tiny", "135m"])
+def test_wide_group_step_is_bitexact(cz, czo, shape, path):
+    """the decode step of ONE WIDE lock-step group against the oracle: every logit of the trait steps, the coder intervals, and a lock-step
+    decode across a re-prime, graph replay and eager.  Two forms: "tiled" = tiled MFMA GEMMs with 64-row tiles + rope kernel + dec_attn with
+    natural-layout output; "np2" = dec_gemm_kernel with 32-row x 64-column blocks (MT = 2, NP = 2), the shape groups of >= 256 streams take"""
+    if shape == "tiny":
+        gcfg, ocfg, V, n_tok, seed = cz.tiny_llama_config(), czo.tiny_llama_config(), 512, 700, 11
+    else:
+        gcfg, ocfg, V, n_tok, seed = cz.smollm2_135m_config(), czo.smollm2_135m_config(), 49152, 40, 0x5EED
+    g = cz.Session("smollm", gcfg, seed=seed, embed_std=0.05 if shape == "tiny" else 0.02, max_streams=6)
+    o = czo.SmolLmSession(ocfg, seed=seed, embed_std=0.05 if shape == "tiny" else 0.02)
+    if path == "tiled":
+        g.debug_set("wide_min_streams", 1)                                # every group, even one stream, takes the tiled-GEMM step
+    else:
+        g.debug_set("wide_min_streams", 0); g.debug_set("dec_wide_rows", 1)   # ... or the wide dec_gemm blocks (process-wide knob: reset below)
+    rng = np.random.default_rng(21)
+    toks = rng.integers(0, V, 30).astype(np.uint32)
+    _eq(g.reprime_with_history_and_get_last_logits_tensor(toks[:1]), o.reprime_logits(toks[:1]), "bos")
+    for i, t in enumerate(toks[1:8]):
+        _eq(g.step_logits_tensor(t), o.step_logits(t), f"wide step {i}")
+    _eq(g.reprime_with_history_and_get_last_logits_tensor(toks[:20]), o.reprime_logits(toks[:20]), "reprime(20)")
+    _eq(g.step_logits_tensor(toks[20]), o.step_logits(toks[20]), "wide step after reprime")
+    lens = [n_tok, n_tok // 2, 3, n_tok, 1]
+    streams = [np.concatenate([[0], rng.integers(0, V, n)]).astype(np.uint32) for n in lens]
+    ref = [o.encode_tokens(s_) for s_ in streams[:2]]
+    pairs = g.encode_tokens_batch(streams)
+    for (lo, hi), (rp, clo, chi, _) in zip(pairs, ref):
+        assert np.array_equal(lo, clo) and np.array_equal(hi, chi)
+    coded = [cz.ac_encode_pairs(lo, hi) for lo, hi in pairs]
+    assert coded[0][0] == ref[0][0]
+    for no_graph in (0, 1):
+        g.debug_set("no_graph", no_graph)
+        outs = g.decode_tokens_batch([p for p, _ in coded], lens)
+        assert np.array_equal(outs[0], o.decode_tokens(ref[0][0], lens[0]))
+        for s_, out, (_, z) in zip(streams, outs, coded):
+            if z == 0:
+                assert np.array_equal(out, s_)
+    g.debug_set("dec_wide_rows", 256)
+    g.close(); o.close()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Tuning aid: lock-step decode steps at a FIXED context length, on one or several concurrent lanes (cz_debug_decode_steps).
 Each config is `name:B=<streams per lane>,L=<lanes>,pos=<context>,x=<0|1: one XCD per lane via a CU-masked stream>,av=<dbg_skip: 1 = no attention, 2 = attention only>,
-fn=<fuse_norm>,g=<1 graph|0 eager>,prof=<1: eager per-family HIP events on lane 0>`.  Prints one JSON line per config."""
+fn=<fuse_norm>,gt=<dec_grid_target>,dw=<dec_wide_rows: dec_gemm blocks of 32 x 64 from this many rows on>,wm=<wide_min_streams: groups at least this wide take the tiled-GEMM step>,mt=<dec_mt_max>,g=<1 graph|0 eager>,prof=<1: eager per-family HIP events on lane 0>`.  Prints one JSON line per config."""
 import argparse
 import ctypes as C
 import json
@@ -12,6 +12,9 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import candlezip_amd as cz
+
+
+WM = [256]
 
 
 def run_config(parent, cfgs, name, B, L, pos, x, av, fn, g, prof, iters, sym):
@@ -26,15 +29,23 @@ def run_config(parent, cfgs, name, B, L, pos, x, av, fn, g, prof, iters, sym):
             s.debug_set("cu_mask_xcd", (k * nx) % 8 + 16 * (nx - 1))
         s.debug_set("dbg_skip", av)
         s.debug_set("fuse_norm", fn)
+        s.debug_set("wide_min_streams", WM[0])
     ms = [0.0] * L; err = []
+    gate = threading.Barrier(L)
 
     def worker(k):
         out = C.c_double()
-        if prof and k == 0:
-            lanes[k].profile_enable(True)
-        rc = lib.cz_debug_decode_steps(lanes[k].h, B, pos, iters, 0 if (prof and k == 0) else g, sym, C.byref(out))
+        gk = 0 if (prof and k == 0) else g
+        rc = lib.cz_debug_decode_steps(lanes[k].h, B, pos, 0, gk, sym, C.byref(out))       # prepare: buffers, graph capture, warm step
         if rc:
             err.append(lib.cz_last_error().decode())
+        if prof and k == 0:
+            lanes[k].profile_enable(True)
+        gate.wait()                                                                          # every lane starts its timed loop together
+        if not rc:
+            rc = lib.cz_debug_decode_steps(lanes[k].h, B, pos, iters, gk, sym, C.byref(out))
+            if rc:
+                err.append(lib.cz_last_error().decode())
         ms[k] = out.value
 
     th = [threading.Thread(target=worker, args=(k,)) for k in range(L)]
@@ -64,12 +75,14 @@ def main():
     parent = cz.Session("smollm", cz.smollm2_135m_config(), seed=0x5EED, embed_std=0.02, max_streams=args.max_streams)
     for c in args.configs:
         name, _, kv = c.partition(":")
-        d = dict(B=128, L=1, pos=767, x=0, av=0, fn=1, g=1, prof=0)
+        d = dict(B=128, L=1, pos=767, x=0, av=0, fn=0, g=1, prof=0, gt=384, mt=8, wm=256, dw=256)
         for item in kv.split(","):
             if item:
                 k, v = item.split("=")
                 d[k] = int(v)
-        run_config(parent, None, name, d["B"], d["L"], d["pos"], d["x"], d["av"], d["fn"], d["g"], d["prof"], args.iters, args.sym)
+        parent.debug_set("dec_grid_target", d["gt"]); parent.debug_set("dec_mt_max", d["mt"])     # (process-wide knobs)
+        WM[0] = d["wm"]; parent.debug_set("dec_wide_rows", d["dw"])
+        run_config(parent, None, name + f"[gt={d['gt']}]", d["B"], d["L"], d["pos"], d["x"], d["av"], d["fn"], d["g"], d["prof"], args.iters, args.sym)
     parent.close()
 
 
