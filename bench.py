@@ -10,8 +10,8 @@ One "step" = one `--window`-token slice of the self-test of EVERY stream: the se
 generation being compressed (cz_encode_tokens_range_batch; the serial arithmetic coder runs when the generation is complete) and
 the lock-step decompress of window w of the generation whose payloads are complete (cz_decode_advance: KV cache, arithmetic-decoder
 state and decoded ids stay in HBM between steps).  Both generations are full 17 408-token samples, so the re-prime sawtooth every
-step sees is the steady-state one whatever K is: K = 17 steps are exactly one 64 KiB sample per stream, and any other K times the
-same configuration.  Every generation's round trip is verified when its last window has been decoded.  Pipeline fill (the compress
+step sees is the steady-state one whatever K is: 17 408 / window steps are exactly one 64 KiB sample per stream, and any other K times the
+same configuration (with the default 256-token window and re-prime interval 512, every second step holds a re-prime).  Every generation's round trip is verified when its last window has been decoded.  Pipeline fill (the compress
 of generation 0) happens before the warmup steps and is not timed.
 
 Contract line (rank 0): metric/value/unit/n_gpus/steps/warmup/ms_per_step/... + "roofline" (the kernel FUNCTION with the largest
@@ -202,13 +202,13 @@ def cpu_baseline(sample_tokens, context, reprime):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=17, help="timed steps; 17 windows of 1024 tokens = one 64 KiB sample per stream")
+    ap.add_argument("--steps", type=int, default=17, help="timed steps; 68 windows of 256 tokens are one 64 KiB sample per stream")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=384, help="streams (64 KiB chunks) per GPU, decoded in lock-step")
-    ap.add_argument("--lanes", type=int, default=3, help="concurrent lock-step decode groups per GPU (library decode lanes)")
-    ap.add_argument("--lane-streams", type=int, default=128, help="streams per lock-step group")
+    ap.add_argument("--streams", type=int, default=1024, help="streams (64 KiB chunks) per GPU, decoded in lock-step (KV cache: 94 MB per stream)")
+    ap.add_argument("--lanes", type=int, default=2, help="concurrent lock-step decode groups per GPU (library decode lanes)")
+    ap.add_argument("--lane-streams", type=int, default=512, help="streams per lock-step group (>= 256: the wide-group decode step)")
     ap.add_argument("--sample-tokens", type=int, default=17408, help="tokens per stream (a 64 KiB enwik8 sample is ~17.4k SmolLM2 tokens)")
-    ap.add_argument("--window", type=int, default=1024, help="tokens per stream and step")
+    ap.add_argument("--window", type=int, default=256, help="tokens per stream and step")
     ap.add_argument("--no-graph", action="store_true", help="launch the decode step eagerly (one AQL packet per submission: for rocprofv3 --pmc)")
     ap.add_argument("--no-events", action="store_true", help="no HIP-event timing inside the timed region (for rocprofv3 --pmc)")
     ap.add_argument("--step-sync", action="store_true", help="with --no-graph: synchronise after every decode step, so that launches never queue up (rocprofv3 --pmc, DESIGN.md §9)")
@@ -332,10 +332,15 @@ def main():
                       "launches": st["launches"], "avg_launch_us": round(1e3 * ms / n, 3), "total_ms": round(ms, 2), "measured_in": where})
             return r
 
+        if per_lane >= 256:      # wide lock-step groups: the layer projections run on gemm_mid_kernel, lm_head and the norms on the big-M kernels
+            FUNCTIONS.pop("dec_gemm_kernel"); FUNCTIONS.pop("dec_rmsnorm_kernel")
+            FUNCTIONS["gemm_mid_kernel"] = (["dec_gemm_plain", "dec_gemm_qkv_rope", "dec_gemm_swiglu"], "mfma", "gemm_mid_kernel<")
+            FUNCTIONS["gemm_bf16w_kernel (decode lm_head)"] = (["dec_gemm_lm_head"], "mfma", "gemm_bf16w_kernel<128, 128, 2, 2, 0>")
+            FUNCTIONS["rmsnorm_kernel"] = (["rmsnorm", "dec_rmsnorm"], "hbm", "rmsnorm_kernel")
         where = (f"eager per-family pass inside bench.py ({min(per_lane, len(mine))} streams x {args.profile_tokens} tokens: the workload's own context sawtooth, up to "
                  "1023 keys; one decode lane); the timed region replays hipGraphs on concurrent lanes")
         by_fn = {fn: merged(prof_all, FUNCTIONS[fn][0]) for fn in FUNCTIONS}
-        dominant = max(by_fn, key=lambda f: by_fn[f]["total_ms"]) if prof_all else "dec_gemm_kernel"
+        dominant = max(by_fn, key=lambda f: by_fn[f]["total_ms"]) if prof_all else "dec_attn_kernel"
         roof = roof_of(dominant, by_fn[dominant], where)
         roof["functions_ms_profile_pass"] = {f: round(v["total_ms"], 2) for f, v in by_fn.items() if v["total_ms"]}
         line = {
@@ -358,8 +363,9 @@ def main():
         }
         if prof_all and dominant != "dec_attn_kernel":
             line["roofline_dec_attention"] = roof_of("dec_attn_kernel", by_fn["dec_attn_kernel"], where)
-        if prof_all and dominant != "dec_gemm_kernel":
-            line["roofline_dec_gemm"] = roof_of("dec_gemm_kernel", by_fn["dec_gemm_kernel"], where)
+        dg = "gemm_mid_kernel" if "gemm_mid_kernel" in FUNCTIONS else "dec_gemm_kernel"
+        if prof_all and dominant != dg:
+            line["roofline_dec_gemm"] = roof_of(dg, by_fn[dg], where)
         if prof_timed:
             line["roofline_mfma_gemm"] = roof_of("gemm_bf16w_kernel", merged(prof_timed, FUNCTIONS["gemm_bf16w_kernel"][0]),
                                                  "HIP events over the timed region (encode + lane-0 re-prime launches, decode lanes competing)")

@@ -26,6 +26,7 @@ struct LlamaModel {
     uint16_t* E = nullptr;             // [vocab][d]  (tied lm_head)
     struct Layer { uint16_t *ln1, *wqkv, *wo, *ln2, *wgu, *wd, *wgu_i; };   // wgu_i: gate|up rows interleaved by 32 for the fused SwiGLU epilogue (big-M path), or null
     uint16_t* blob_gu = nullptr;       // storage of the wgu_i copies
+    uint16_t* blob_k2 = nullptr;       // the layer matrices packed for the mid-M GEMM (kernels_gemm_mid.hip); wgu's slot holds the interleaved gate|up rows
     std::vector<Layer> L;
     uint16_t* lnf = nullptr;
     float *rope_cos = nullptr, *rope_sin = nullptr;   // [max_pos][32]
@@ -61,9 +62,9 @@ struct cz_session {
     // packed-row work buffers
     DevBuf tok, x, xn, qkv, gu, h, seqd, roped, rowidx, sym, clo, chi, xl, logits, payload, outids, decst;
     size_t max_batch_rows = 98304, logit_batch_rows = 8192;
-    int force_big_gemm = 0, serial_cdf = 0, decode_v1 = 0, no_graph = 0, fuse_norm = 0, step_sync = 0, dbg_skip = 0, wide_min_streams = 256;
+    int force_big_gemm = 0, serial_cdf = 0, decode_v1 = 0, no_graph = 0, fuse_norm = 0, step_sync = 0, dbg_skip = 0, wide_min_streams = 256, wide_mode = 3;
     hipGraph_t dbg_g = nullptr; hipGraphExec_t dbg_ge = nullptr;      // cz_debug_decode_steps
-    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; int graph_B = 0; unsigned long long graph_gen = 0;
+    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; int graph_B = 0, graph_max_nk = 0; unsigned long long graph_gen = 0;
     unsigned long long devbuf_gen = 0, graph_launch_ns = 0, graph_launch_cpu_ns = 0, graph_launch_idle_ns = 0; int probe_launch = 0;
     unsigned* fallback_dev = nullptr;   // rows the exact-parallel CDF kernel handed to the serial walk
     double* cdf_scratch = nullptr;      // spill rows of the exact-parallel CDF kernel (cz_cdf_par_scratch_bytes)

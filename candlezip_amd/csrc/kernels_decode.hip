@@ -459,11 +459,14 @@ __global__ __launch_bounds__(DA_THREADS, 4) void dec_attn_kernel(const float* __
     const int kvh = blockIdx.y;
     gfloat* Kb = (gfloat*)(sd.k + kv_off + (sd.kt_stride ? (size_t)kvh * 64 * sd.kt_stride : (size_t)kvh * 64));
     gfloat* Vb = (gfloat*)(sd.v + kv_off + kvh * 64);
-    float* qs = smem;                                   // [DA_MAXREP][64]
-    float* S = qs + DA_MAXREP * 64;                     // [DA_MAXREP][s_stride]  e, then p
-    float* part = S + DA_MAXREP * s_stride;             // [32][DA_MAXREP][64]   chunk partials of P.V
-    float* red = part + 32 * DA_MAXREP * 64;            // [DA_WAVES][DA_MAXREP] local maxima
-    float* csum = red + DA_WAVES * DA_MAXREP;           // [DA_MAXREP][32]       chunk sums of e
+    // LDS sized by the launch for `rep` heads and the longest context the caller will reach (s_stride = 64 * chunks + 4): 26 KB at 1024
+    // keys, rep 3 — small enough that a GEMM block of another decode lane fits on the CU beside two attention blocks
+    const int nch_max = (s_stride - 4) >> 6;
+    float* qs = smem;                                   // [rep][64]
+    float* S = qs + rep * 64;                           // [rep][s_stride]  e, then p
+    float* part = S + rep * s_stride;                   // [nch_max][rep][64]   chunk partials of P.V
+    float* red = part + nch_max * rep * 64;             // [DA_WAVES][DA_MAXREP] local maxima
+    float* csum = red + DA_WAVES * DA_MAXREP;           // [rep][32]       chunk sums of e
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < rep * 64) qs[tid] = Q[(size_t)sd.row0 * ldq + (kvh * rep + (tid >> 6)) * 64 + (tid & 63)];
     __syncthreads();
@@ -599,27 +602,28 @@ __global__ __launch_bounds__(DA_THREADS, 4) void dec_attn_kernel(const float* __
                 }
             }
 #pragma unroll
-            for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) part[(c * DA_MAXREP + h) * 64 + lane] = acc[h];
+            for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) part[(c * rep + h) * 64 + lane] = acc[h];
         }
     }
     __syncthreads();
     if (tid < rep * 64) {
         const int h = tid >> 6, dd = tid & 63;
-        float t = part[(0 * DA_MAXREP + h) * 64 + dd];
-        for (int c = 1; c < nch; ++c) t = t + part[(c * DA_MAXREP + h) * 64 + dd];
+        float t = part[(0 * rep + h) * 64 + dd];
+        for (int c = 1; c < nch; ++c) t = t + part[(c * rep + h) * 64 + dd];
         const int col = (kvh * rep + h) * 64 + dd;
         O[(size_t)sd.row0 * ldo + (out_kq ? kq_index(col) : col)] = t;          // kq layout feeds dec_gemm_kernel's o-projection, natural layout the tiled GEMM
     }
 }
 static int da_s_stride(int max_nk) { return ((max_nk + 63) / 64) * 64 + 4; }
-static size_t da_smem(int max_nk) {
-    return (size_t)(DA_MAXREP * 64 + DA_MAXREP * da_s_stride(max_nk) + 32 * DA_MAXREP * 64 + DA_WAVES * DA_MAXREP + DA_MAXREP * 32) * sizeof(float);
+static size_t da_smem(int max_nk, int rep) {
+    const int nch = (max_nk + 63) / 64;
+    return (size_t)(rep * 64 + rep * da_s_stride(max_nk) + nch * rep * 64 + DA_WAVES * DA_MAXREP + rep * 32) * sizeof(float);
 }
 hipError_t cz_dec_attn_prepare(int max_nk) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk));
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk));
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk));
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk, 1));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk, 2));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk, 3));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk, 4));
     return e;
 }
 hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nstreams, int max_nk,
@@ -628,7 +632,7 @@ hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O,
     const int rep = n_heads / n_kv;
     if (rep < 1 || rep > DA_MAXREP || max_nk > 2048) return hipErrorInvalidValue;
     const dim3 grid(nstreams, n_kv), block(DA_THREADS);
-    const size_t smem = da_smem(max_nk); const int ss = da_s_stride(max_nk);
+    const size_t smem = da_smem(max_nk, rep); const int ss = da_s_stride(max_nk);
     switch (rep) {
         case 1: hipLaunchKernelGGL(dec_attn_kernel<1>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;
         case 2: hipLaunchKernelGGL(dec_attn_kernel<2>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;

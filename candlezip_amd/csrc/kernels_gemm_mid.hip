@@ -1,0 +1,218 @@
+// kernels_gemm_mid.hip — C[M,N] = A[M,K] (f32) x W[N,K]^T (bf16) for a FEW HUNDRED rows: the projections of one wide lock-step decode
+// group (M = 256..1024 streams), in the canonical reduction order (chunks of 64 k, fmaf chain inside a chunk == an MFMA chain, chunk
+// partials added left to right in f32).
+//
+// Why a third GEMM shape.  At these row counts a projection is 0.3-2.7 GFLOP: 2-17 us of the f32 MFMA peak, spread over 256 CUs only if
+// it is cut into ~500+ pieces.  The big-M kernel's tiles (>= 64 x 64, K walked serially) give 54-288 blocks that each walk 9-24 K tiles
+// alone on a CU; dec_gemm_kernel splits K over the waves of a block but re-reads the activations once per 32 output columns and keeps
+// one accumulator chain per operand load.  Here:
+//   * block = ONE 32 x (32 TN) output tile, four waves = four K GROUPS: wave g owns K tiles g, g+4, ...  The M/32 x N/(32 TN) grid is
+//     432 blocks for the 768 x 576 o-projection, 2304 for gate|up.
+//   * the ordered sum of the chunk partials crosses the waves through LDS: every round (4 K tiles) waves 1..3 park their partial tiles
+//     in a double-buffered slot, ONE barrier, and wave 0 adds them — in K order — to the running total while the next round's MFMAs are
+//     already issued.  No wave ever waits for another one's MFMAs inside a round.
+//   * weights are read straight into MFMA operand registers from a copy packed for v_mfma_f32_32x32x2_f32 ("k2": per row and 64-k chunk
+//     the even k, then the odd k, so that lane (n, h) loads its 32 operands k = 2t + h as 64 contiguous bytes); only the activations
+//     pass through LDS (a wave-private 32 x 64 tile: no block barrier for staging).
+// Bound: f32 MFMA (157.3 TFLOP/s).  Algorithmic flops per launch = 2 M N K.
+#include "cz_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MID_LDK 68   // LDS row stride of the activation tile in floats (64 + 4: ds_read_b128 by 16 consecutive rows is conflict-free)
+
+// Wk[n][c*64 + h*32 + t] = W[n][c*64 + 2t + h]
+__global__ void k2_pack_kernel(const uint16_t* __restrict__ W, uint16_t* __restrict__ Wk, size_t N, int K) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < N * (size_t)K; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / K; const int k = (int)(i % K);
+        Wk[n * K + (k & ~63) + (k & 1) * 32 + ((k & 63) >> 1)] = W[i];
+    }
+}
+hipError_t cz_launch_k2_pack(hipStream_t st, const uint16_t* W, uint16_t* Wk, size_t N, int K) {
+    if (K % 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k2_pack_kernel, dim3(2048), dim3(256), 0, st, W, Wk, N, K);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ int mid_xcd_remap(int bid, int nblocks) {    // blocks b and b + 8 share an XCD (speed only): contiguous tile ranges per XCD
+    int q = nblocks >> 3, r = nblocks & 7, x = bid & 7;
+    int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+// EPI = 0: C = A.W^T (+ R).  EPI = 1 (TN = 2): W rows interleaved gate|up by 32 (cz_launch_gu_interleave): H[M][N/2] = silu(gate) * up.
+template <int TN, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_mid_kernel(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Wk,
+                                                          float* __restrict__ C, int ldc, const float* __restrict__ R, int ldr,
+                                                          int M, int N, int K, int nbx, int nblocks) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* As = smem + wave * (32 * MID_LDK);                            // wave-private activation tile [32][MID_LDK]
+    float* slots = smem + 4 * (32 * MID_LDK);                            // [2][3][TN][16][64] partial tiles of waves 1..3
+    const int sid = mid_xcd_remap(blockIdx.x, nblocks);
+    const int bm = sid / nbx, bn = sid % nbx;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int nk = K >> 6, rounds = (nk + 3) >> 2;
+    const int srow = lane >> 3, sg = lane & 7;                           // staging: 8 rows x 8 k-groups per pass, 4 passes
+
+    f32x4 ra[4][2];
+    uint4 rb[TN][4];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = bm * 32 + p * 8 + srow;
+            if (row < M) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(A + (size_t)row * lda + kt * 64 + sg * 8);
+                ra[p][0] = src[0]; ra[p][1] = src[1];
+            } else { ra[p][0] = f32x4{0, 0, 0, 0}; ra[p][1] = f32x4{0, 0, 0, 0}; }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const uint4* src = reinterpret_cast<const uint4*>(Wk + (size_t)(bn * (32 * TN) + j * 32 + lr) * K + kt * 64 + lh * 32);
+            rb[j][0] = src[0]; rb[j][1] = src[1]; rb[j][2] = src[2]; rb[j][3] = src[3];
+        }
+    };
+    // LDS image (as gemm_bf16w_kernel): within every group of 8 k the even k first, then the odd k, so that the b128 read of lane-half h
+    // at 8g + 4h yields k = 8g + 2j + h, j = 0..3 = the A operands of MFMA steps 4g + j
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float* dst = As + (p * 8 + srow) * MID_LDK + sg * 8;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{ra[p][0][0], ra[p][0][2], ra[p][1][0], ra[p][1][2]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{ra[p][0][1], ra[p][0][3], ra[p][1][1], ra[p][1][3]};
+        }
+    };
+
+    f32x16 tot[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[j][r] = 0.0f;
+    if (wave < nk) load_tile(wave);
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int kt = rd * 4 + wave;
+        f32x16 acc[TN];
+        if (kt < nk) {
+            unsigned wb[TN][16];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { wb[j][4 * q] = rb[j][q].x; wb[j][4 * q + 1] = rb[j][q].y; wb[j][4 * q + 2] = rb[j][q].z; wb[j][4 * q + 3] = rb[j][q].w; }
+            store_tile();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0xc07f);                        // this wave's LDS writes are visible to its own lanes (lgkmcnt(0))
+            if (kt + 4 < nk) load_tile(kt + 4);                         // next tile of this wave in flight under the MFMA chain
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 af = *reinterpret_cast<const f32x4*>(As + lr * MID_LDK + g * 8 + lh * 4);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int t = 4 * g + s;                              // MFMA step: k = 2t + lh
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const unsigned w = wb[j][t >> 1];
+                        const float bv = (t & 1) ? cz_bits_f32(w & 0xffff0000u) : cz_bits_f32(w << 16);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bv, acc[j], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0xc07f);                        // (the reads of As are done before the next round overwrites it)
+        }
+        if (wave == 0) {
+            // chunk partials of the previous round's waves 1..3, in K order, then this round's own chunk
+            if (rd > 0) {
+                const float* sp = slots + ((rd - 1) & 1) * (3 * TN * 1024);
+#pragma unroll
+                for (int w = 0; w < 3; ++w)
+                    if ((rd - 1) * 4 + 1 + w < nk) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) tot[j][r] = tot[j][r] + sp[((w * TN + j) * 16 + r) * 64 + lane];
+                    }
+            }
+            if (kt < nk) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tot[j][r] = rd == 0 ? acc[j][r] : tot[j][r] + acc[j][r];
+            }
+        } else if (kt < nk) {
+            float* sp = slots + (rd & 1) * (3 * TN * 1024) + (wave - 1) * TN * 1024;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sp[(j * 16 + r) * 64 + lane] = acc[j][r];
+        }
+        __syncthreads();                                                // one barrier per round: the slots of round rd are complete
+    }
+    if (wave != 0) return;
+    {
+        const int rd = rounds;
+        const float* sp = slots + ((rd - 1) & 1) * (3 * TN * 1024);
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+            if ((rd - 1) * 4 + 1 + w < nk) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tot[j][r] = tot[j][r] + sp[((w * TN + j) * 16 + r) * 64 + lane];
+            }
+    }
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (EPI == 1) {
+        const int hcol = (bn * (32 * TN)) / 2 + lr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < M) C[(size_t)row * ldc + hcol] = cz_siluf(tot[0][r]) * tot[TN - 1][r];      // silu(gate) * up (llama.rs MLP)
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = bn * (32 * TN) + j * 32 + lr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < M) {
+                float v = tot[j][r];
+                if (R) v = v + R[(size_t)row * ldr + col];
+                C[(size_t)row * ldc + col] = v;
+            }
+        }
+    }
+}
+
+template <int TN, int EPI>
+static hipError_t launch_mid(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* C, int ldc, const float* R, int ldr, int M, int N, int K) {
+    static bool attr_set = false;
+    const size_t smem = (size_t)(4 * 32 * MID_LDK + 2 * 3 * TN * 1024) * sizeof(float);
+    auto kern = gemm_mid_kernel<TN, EPI>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nbx = N / (32 * TN), nby = (M + 31) / 32, nblocks = nbx * nby;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, st, A, lda, Wk, C, ldc, R, ldr, M, N, K, nbx, nblocks);
+    return hipGetLastError();
+}
+// C[M][N] = A . W^T (+ R); Wk = the k2-packed copy of W
+hipError_t cz_launch_gemm_mid(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* C, int ldc, const float* R, int ldr, int M, int N, int K) {
+    if (M <= 0) return hipSuccess;
+    if (K % 64 != 0 || N % 32 != 0) return hipErrorInvalidValue;
+    return launch_mid<1, 0>(st, A, lda, Wk, C, ldc, R, ldr, M, N, K);
+}
+// H[M][f] = silu(A . Wgate^T) * (A . Wup^T); Wk = the k2-packed copy of the gate|up rows interleaved by 32 (cz_launch_gu_interleave)
+hipError_t cz_launch_gemm_mid_swiglu(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* H, int ldh, int M, int f, int K) {
+    if (M <= 0) return hipSuccess;
+    if (K % 64 != 0 || f % 32 != 0) return hipErrorInvalidValue;
+    return launch_mid<2, 1>(st, A, lda, Wk, H, ldh, nullptr, 0, M, 2 * f, K);
+}

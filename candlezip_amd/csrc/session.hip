@@ -254,6 +254,19 @@ static cz_status build_llama(cz_session* s, const cz_model_desc* desc) {
             HIPCHK(cz_launch_gu_interleave(s->stream, m.L[l].wgu, m.L[l].wgu_i, (int)f, (int)d));
         }
     }
+    // wide lock-step groups: the layer matrices packed for the mid-M GEMM (kernels_gemm_mid.hip), same offsets as blob minus the embedding
+    {
+        const size_t off0 = (size_t)(m.L[0].ln1 - m.blob);
+        HIPCHK(hipMalloc((void**)&m.blob_k2, (total - off0) * 2));
+        auto k2 = [&](const uint16_t* w) { return m.blob_k2 + ((size_t)(w - m.blob) - off0); };
+        for (size_t l = 0; l < L; ++l) {
+            const LlamaModel::Layer& y = m.L[l];
+            HIPCHK(cz_launch_k2_pack(s->stream, y.wqkv, k2(y.wqkv), d + 2 * kvd, (int)d));
+            HIPCHK(cz_launch_k2_pack(s->stream, y.wo, k2(y.wo), d, (int)d));
+            HIPCHK(cz_launch_k2_pack(s->stream, y.wd, k2(y.wd), d, (int)f));
+            if (y.wgu_i) HIPCHK(cz_launch_k2_pack(s->stream, y.wgu_i, k2(y.wgu), 2 * f, (int)d));     // (the interleaved gate|up rows, in wgu's slot)
+        }
+    }
     HIPCHK(hipStreamSynchronize(s->stream));
     return CZ_OK;
 }
@@ -401,9 +414,20 @@ static cz_status llama_step_wide(cz_session* s, int B, int pos, int max_nk) {
     const int d = c.d_model, f = c.d_ffn, kvd = c.n_kv_heads * 64, nq = d + 2 * kvd;
     CZCHK(s->x.ensure((size_t)B * d * 4)); CZCHK(s->xn.ensure((size_t)B * d * 4)); CZCHK(s->qkv.ensure((size_t)B * nq * 4)); CZCHK(s->h.ensure((size_t)B * f * 4));
     const bool fused_gu = m.L[0].wgu_i != nullptr;
-    if (!fused_gu) CZCHK(s->gu.ensure((size_t)B * 2 * f * 4));
+    const bool hybrid = s->wide_mode == 2;
+    if (!fused_gu && !hybrid) CZCHK(s->gu.ensure((size_t)B * 2 * f * 4));
     float *x = (float*)s->x.p, *xn = (float*)s->xn.p, *qkv = (float*)s->qkv.p, *gu = (float*)s->gu.p, *h = (float*)s->h.p;
     hipStream_t st = s->stream;
+    const bool mid = s->wide_mode == 3 && fused_gu && m.blob_k2;     // the K-group GEMM (kernels_gemm_mid.hip) for the four layer projections
+    const size_t off0 = (size_t)(m.L[0].ln1 - m.blob);
+    auto k2 = [&](const uint16_t* w) { return m.blob_k2 + ((size_t)(w - m.blob) - off0); };
+    auto gemm_mid = [&](int kind, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R, int N, int K) -> hipError_t {
+        s->prof_begin(kind);
+        hipError_t e = cz_launch_gemm_mid(st, A, lda, k2(W), C, ldc, R, ldc, B, N, K);
+        s->prof_end(2.0 * B * (double)N * K, (double)N * K * 2 + (double)B * (N + K) * 4);
+        return e;
+    };
+    auto dec = [&](const uint16_t* w) { return m.blob_dec + (w - m.blob); };
     auto gemm = [&](int kind, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R, int N, int K) -> hipError_t {
         s->prof_begin(kind);
         hipError_t e = cz_launch_gemm(st, A, lda, W, C, ldc, R, ldc, B, N, K, 1);
@@ -416,17 +440,33 @@ static cz_status llama_step_wide(cz_session* s, int B, int pos, int max_nk) {
         const size_t kv_off = (size_t)l * s->kv_layer_stride;
         if (!(s->dbg_skip & 2)) {
             s->prof_begin(PK_DEC_NORM); HIPCHK(cz_launch_rmsnorm(st, x, d, y.ln1, xn, d, B, d, c.rms_eps, nullptr)); s->prof_end(0, (double)B * d * 8);
-            HIPCHK(gemm(PK_DEC_GEMM_QKV, xn, d, y.wqkv, qkv, nq, nullptr, nq, d));
+            if (mid) HIPCHK(gemm_mid(PK_DEC_GEMM_QKV, xn, d, y.wqkv, qkv, nq, nullptr, nq, d));
+            else HIPCHK(gemm(PK_DEC_GEMM_QKV, xn, d, y.wqkv, qkv, nq, nullptr, nq, d));
             s->prof_begin(PK_ROPE);                                                        // q rotated in place; k (rotated) and v go to the cache rows at *pos_dev
             HIPCHK(cz_launch_rope(st, qkv, nq, s->step_roped, B, 1, c.n_heads, c.n_kv_heads, m.rope_cos, m.rope_sin, kv_off, s->pos_dev));
             s->prof_end(0, (double)B * nq * 8);
         }
         if (!(s->dbg_skip & 1)) {
             s->prof_begin(PK_DEC_ATTN);
-            HIPCHK(cz_launch_dec_attn(st, qkv, nq, xn, d, s->step_seqd, B, max_nk, c.n_heads, c.n_kv_heads, kv_off, s->pos_dev, 0));
+            HIPCHK(cz_launch_dec_attn(st, qkv, nq, xn, d, s->step_seqd, B, max_nk, c.n_heads, c.n_kv_heads, kv_off, s->pos_dev, hybrid ? 1 : 0));
             s->prof_end(4.0 * 64 * c.n_heads * (double)B * (pos + 1), 2.0 * B * (double)(pos + 1) * kvd * 4);
         }
         if (s->dbg_skip & 2) continue;
+        if (hybrid) {     // o-projection, gate|up and down-projection on dec_gemm_kernel's 32 x 64 blocks (K split over the waves of a block): at a few
+                          // hundred rows they beat the tiled kernel, whose 64 x 64 tiles walk K serially (the down-projection has 24 K tiles)
+            s->prof_begin(PK_DEC_GEMM); HIPCHK(cz_launch_dec_gemm_plain(st, xn, d, dec(y.wo), x, d, x, B, d, d, nullptr, 0.0f)); s->prof_end(2.0 * B * (double)d * d, (double)d * d * 2);
+            s->prof_begin(PK_DEC_NORM); HIPCHK(cz_launch_dec_rmsnorm(st, x, d, y.ln2, xn, d, B, d, c.rms_eps)); s->prof_end(0, (double)B * d * 8);
+            s->prof_begin(PK_DEC_GEMM_GU); HIPCHK(cz_launch_dec_gemm_swiglu(st, xn, d, dec(y.wgu), h, f, B, f, d, nullptr, 0.0f)); s->prof_end(4.0 * B * (double)f * d, (double)f * d * 4);
+            s->prof_begin(PK_DEC_GEMM); HIPCHK(cz_launch_dec_gemm_plain(st, h, f, dec(y.wd), x, d, x, B, d, f, nullptr, 0.0f)); s->prof_end(2.0 * B * (double)d * f, (double)d * f * 2);
+            continue;
+        }
+        if (mid) {
+            HIPCHK(gemm_mid(PK_DEC_GEMM, xn, d, y.wo, x, d, x, d, d));                      // x = attn_out . Wo^T + x
+            s->prof_begin(PK_DEC_NORM); HIPCHK(cz_launch_rmsnorm(st, x, d, y.ln2, xn, d, B, d, c.rms_eps, nullptr)); s->prof_end(0, (double)B * d * 8);
+            s->prof_begin(PK_DEC_GEMM_GU); HIPCHK(cz_launch_gemm_mid_swiglu(st, xn, d, k2(y.wgu), h, f, B, f, d)); s->prof_end(4.0 * B * (double)f * d, (double)f * d * 4);
+            HIPCHK(gemm_mid(PK_DEC_GEMM, h, f, y.wd, x, d, x, d, f));                       // x = mlp_out + x
+            continue;
+        }
         HIPCHK(gemm(PK_DEC_GEMM, xn, d, y.wo, x, d, x, d, d));                              // x = attn_out . Wo^T + x
         s->prof_begin(PK_DEC_NORM); HIPCHK(cz_launch_rmsnorm(st, x, d, y.ln2, xn, d, B, d, c.rms_eps, nullptr)); s->prof_end(0, (double)B * d * 8);
         if (fused_gu) {
@@ -494,7 +534,7 @@ static void destroy_step_graph(cz_session* s) {
     if (s->graph) { hipGraphDestroy(s->graph); s->graph = nullptr; }
     s->graph_B = 0;
 }
-static cz_status build_step_graph(cz_session* s, int B) {
+static cz_status build_step_graph(cz_session* s, int B, int max_nk) {
     destroy_step_graph(s);
     s->graph_gen = s->devbuf_gen;
     const cz_llama_config& c = s->llama.cfg;
@@ -502,13 +542,13 @@ static cz_status build_step_graph(cz_session* s, int B) {
     const unsigned long long* step_dev = reinterpret_cast<const unsigned long long*>(s->pos_dev + 2);
     const bool prof = s->prof_on; s->prof_on = false;            // no events inside a captured region
     // every buffer the captured kernels touch must exist before capture starts
-    cz_status rc = llama_step_any(s, B, 0, CZ_MAX_CTX);
+    cz_status rc = llama_step_any(s, B, 0, max_nk);
     if (rc != CZ_OK) { s->prof_on = prof; return rc; }
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
     hipError_t e = cz_launch_decode_symbol(s->stream, s->step_logits, c.vocab, dst, s->step_sym, B, c.vocab, 0, 0ull, s->fallback_dev, step_dev, s->cdf_scratch);
     if (e == hipSuccess) e = hipMemcpyAsync(s->tok.p, s->step_sym, (size_t)B * 4, hipMemcpyDeviceToDevice, s->stream);
-    if (e == hipSuccess) rc = llama_step_any(s, B, 0, CZ_MAX_CTX);
+    if (e == hipSuccess) rc = llama_step_any(s, B, 0, max_nk);
     if (e == hipSuccess && rc == CZ_OK) { hipLaunchKernelGGL(inc_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev); e = hipGetLastError(); }
     hipGraph_t g = nullptr;
     hipError_t e2 = hipStreamEndCapture(s->stream, &g);
@@ -520,7 +560,7 @@ static cz_status build_step_graph(cz_session* s, int B) {
     }
     s->graph = g;
     HIPCHK(hipGraphInstantiate(&s->graph_exec, s->graph, nullptr, nullptr, 0));
-    s->graph_B = B;
+    s->graph_B = B; s->graph_max_nk = max_nk;
     return CZ_OK;
 }
 
@@ -759,9 +799,21 @@ static cz_status decode_llama_begin(cz_session* s, int B, const uint8_t* const* 
     const unsigned dec_kinds = (1u << PK_DECODE) | (1u << PK_DEC_GEMM) | (1u << PK_DEC_GEMM_QKV) | (1u << PK_DEC_GEMM_GU) | (1u << PK_DEC_GEMM_HEAD) | (1u << PK_DEC_ATTN) | (1u << PK_DEC_NORM) | (1u << PK_EMBED);
     const bool prof_decode = s->prof_on && (s->prof_mask & dec_kinds);
     const bool use_graph = !s->no_graph && !s->decode_v1 && !s->serial_cdf && !prof_decode && c.n_heads / c.n_kv_heads <= 4;
-    if (use_graph && (s->graph_B != B || s->graph_gen != s->devbuf_gen)) {
-        CZCHK(build_step_graph(s, B));
-        if (s->graph_gen != s->devbuf_gen) CZCHK(build_step_graph(s, B));                     // the dry run itself grew a buffer: capture again
+    // longest context this run reaches (the schedule is known up front): it sizes the attention kernel's LDS inside the captured graph, and
+    // with it how many blocks of other lanes' kernels fit on a CU beside the attention blocks
+    int max_nk = 2;
+    {
+        size_t ip = 1, mx = 1;
+        for (size_t i = 0; i < max_tc; ++i) {
+            if (ip >= ec && (i % R) == 0 && i > 0) ip = i + 1 > ec ? ec : i + 1;
+            if (ip > mx) mx = ip;
+            ip += 1;
+        }
+        max_nk = (int)std::min<size_t>(mx + 2, CZ_MAX_CTX);
+    }
+    if (use_graph && (s->graph_B != B || s->graph_gen != s->devbuf_gen || s->graph_max_nk != max_nk)) {
+        CZCHK(build_step_graph(s, B, max_nk));
+        if (s->graph_gen != s->devbuf_gen) CZCHK(build_step_graph(s, B, max_nk));            // the dry run itself grew a buffer: capture again
         CZCHK(llama_step(s, B, 0));                                                          // the dry run clobbered the BOS logits
     }
     hipLaunchKernelGGL(set_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, 1, 0ull);
@@ -878,13 +930,13 @@ extern "C" void cz_session_close(cz_session* s) {
     if (s->fork_of) { auto& v = s->fork_of->forks; v.erase(std::remove(v.begin(), v.end(), s), v.end()); }
     for (cz_session* f : s->forks) {                                // forks outlive their parent only as husks: no weights, every call fails
         f->fork_of = nullptr; f->orphan = true;
-        f->llama.blob = f->llama.blob_dec = f->llama.blob_gu = nullptr; f->llama.rope_cos = f->llama.rope_sin = nullptr;
+        f->llama.blob = f->llama.blob_dec = f->llama.blob_gu = f->llama.blob_k2 = nullptr; f->llama.rope_cos = f->llama.rope_sin = nullptr;
     }
     s->forks.clear();
     hipSetDevice(s->device);
     for (cz_session* l : s->lanes) cz_session_close(l);
     s->lanes.clear();
-    if (s->is_lane) { s->llama.blob = s->llama.blob_dec = s->llama.blob_gu = nullptr; s->llama.rope_cos = s->llama.rope_sin = nullptr; }   // the weights belong to the parent
+    if (s->is_lane) { s->llama.blob = s->llama.blob_dec = s->llama.blob_gu = s->llama.blob_k2 = nullptr; s->llama.rope_cos = s->llama.rope_sin = nullptr; }   // the weights belong to the parent
     if (s->stream) hipStreamSynchronize(s->stream);
     destroy_step_graph(s);
     if (s->dbg_ge) hipGraphExecDestroy(s->dbg_ge);
@@ -894,7 +946,7 @@ extern "C" void cz_session_close(cz_session* s) {
     DevBuf* bufs[] = {&s->tok, &s->x, &s->xn, &s->qkv, &s->gu, &s->h, &s->seqd, &s->roped, &s->rowidx, &s->sym, &s->clo, &s->chi, &s->xl,
                       &s->logits, &s->payload, &s->outids, &s->decst};
     for (auto b : bufs) b->release();
-    void* ptrs[] = {s->cdf_scratch, s->fallback_dev, s->llama.blob_gu, s->llama.blob_dec, s->llama.blob, s->llama.rope_cos, s->llama.rope_sin, s->kvcache, s->pos_dev, s->step_seqd, s->step_roped, s->step_rows,
+    void* ptrs[] = {s->cdf_scratch, s->fallback_dev, s->llama.blob_gu, s->llama.blob_k2, s->llama.blob_dec, s->llama.blob, s->llama.rope_cos, s->llama.rope_sin, s->kvcache, s->pos_dev, s->step_seqd, s->step_roped, s->step_rows,
                     s->step_logits, s->step_sym};
     for (auto p : ptrs) if (p) { hipError_t e = hipFree(p); (void)e; }
     cz_rwkv7_destroy(s);
@@ -958,7 +1010,7 @@ static cz_status make_lane(cz_session* p, cz_session** out) {
 }
 static void lane_inherit(const cz_session* s, cz_session* ls) {   // a lane runs with its parent's knobs
     ls->kv_ctx_cap = s->kv_ctx_cap; ls->serial_cdf = s->serial_cdf; ls->decode_v1 = s->decode_v1; ls->no_graph = s->no_graph; ls->force_big_gemm = s->force_big_gemm;
-    ls->max_batch_rows = s->max_batch_rows; ls->logit_batch_rows = s->logit_batch_rows; ls->step_sync = s->step_sync; ls->fuse_norm = s->fuse_norm; ls->wide_min_streams = s->wide_min_streams; ls->dbg_skip = s->dbg_skip;
+    ls->max_batch_rows = s->max_batch_rows; ls->logit_batch_rows = s->logit_batch_rows; ls->step_sync = s->step_sync; ls->fuse_norm = s->fuse_norm; ls->wide_min_streams = s->wide_min_streams; ls->wide_mode = s->wide_mode; ls->dbg_skip = s->dbg_skip;
 }
 // run `n_streams` streams as groups of <= max_streams on up to max_lanes lanes; group(ls, off, count) processes streams [off, off + count)
 template <class GroupFn>
@@ -1174,7 +1226,7 @@ extern "C" cz_status cz_debug_decode_steps(cz_session* s, int B, int pos, int it
     const cz_llama_config& c = s->llama.cfg;
     auto one = [&]() -> cz_status {
         if (with_symbol) HIPCHK(cz_launch_decode_symbol(s->stream, s->step_logits, c.vocab, (cz_dec_state*)s->decst.p, s->step_sym, B, c.vocab, 0, 0ull, s->fallback_dev, nullptr, s->cdf_scratch));
-        return llama_step_any(s, B, pos, use_graph ? CZ_MAX_CTX : pos + 1);
+        return llama_step_any(s, B, pos, use_graph ? (pos + 1 <= 1024 ? 1024 : CZ_MAX_CTX) : pos + 1);
     };
     if (iters <= 0) {
         CZCHK(ensure_streams(s, B));
@@ -1253,6 +1305,7 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "cu_mask_xcd")) return set_stream_xcd(s, (int)(value % 16), (int)(value / 16) + 1);   // value = first_xcd + 16 * (n_xcd - 1); -1: no mask
     else if (!strcmp(key, "step_sync")) s->step_sync = (int)value;
     else if (!strcmp(key, "wide_min_streams")) s->wide_min_streams = (int)value;
+    else if (!strcmp(key, "wide_mode")) s->wide_mode = (int)value;
     else if (!strcmp(key, "gemm_mid_rows")) g_gemm_mid_rows = (int)value;
     else if (!strcmp(key, "dec_wide_rows")) g_dec_wide_rows = (int)value;
     else if (!strcmp(key, "dbg_skip")) s->dbg_skip = (int)value;          // tools/bench_decode_step.py: 1 = no attention, 2 = no GEMMs/norms (timing only; results are garbage)

@@ -169,12 +169,14 @@ def _eq(a, b, what):
     assert n == 0, f"{what}: {n}/{a.size} logits differ"
 
 
-@pytest.mark.parametrize("path", ["tiled", "np2"])
+@pytest.mark.parametrize("path", ["tiled", "np2", "hybrid", "mid"])
 @pytest.mark.parametrize("shape", ["tiny", "135m"])
 def test_wide_group_step_is_bitexact(cz, czo, shape, path):
     """the decode step of ONE WIDE lock-step group against the oracle: every logit of the trait steps, the coder intervals, and a lock-step
     decode across a re-prime, graph replay and eager.  Two forms: "tiled" = tiled MFMA GEMMs with 64-row tiles + rope kernel + dec_attn with
-    natural-layout output; "np2" = dec_gemm_kernel with 32-row x 64-column blocks (MT = 2, NP = 2), the shape groups of >= 256 streams take"""
+    natural-layout output; "np2" = dec_gemm_kernel with 32-row x 64-column blocks (MT = 2, NP = 2), the shape groups of >= 256 streams take;
+    "hybrid" = tiled QKV / lm_head projections, the rest on the 32 x 64 blocks; "mid" = gemm_mid_kernel (32 x 32 tiles, four K groups per
+    block, ordered hand-off of the chunk partials) for the layer projections"""
     if shape == "tiny":
         gcfg, ocfg, V, n_tok, seed = cz.tiny_llama_config(), czo.tiny_llama_config(), 512, 700, 11
     else:
@@ -183,6 +185,10 @@ def test_wide_group_step_is_bitexact(cz, czo, shape, path):
     o = czo.SmolLmSession(ocfg, seed=seed, embed_std=0.05 if shape == "tiny" else 0.02)
     if path == "tiled":
         g.debug_set("wide_min_streams", 1)                                # every group, even one stream, takes the tiled-GEMM step
+    elif path == "mid":                                                   # the K-group GEMM (kernels_gemm_mid.hip) for the four layer projections
+        g.debug_set("wide_min_streams", 1); g.debug_set("wide_mode", 3)
+    elif path == "hybrid":                                                # tiled QKV / lm_head, dec_gemm 32 x 64 blocks for the other projections
+        g.debug_set("wide_min_streams", 1); g.debug_set("wide_mode", 2); g.debug_set("dec_wide_rows", 1)
     else:
         g.debug_set("wide_min_streams", 0); g.debug_set("dec_wide_rows", 1)   # ... or the wide dec_gemm blocks (process-wide knob: reset below)
     rng = np.random.default_rng(21)

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import candlezip_amd as cz
 
 
-WM = [256]
+WM = [256, 1]
 
 
 def run_config(parent, cfgs, name, B, L, pos, x, av, fn, g, prof, iters, sym):
@@ -29,7 +29,7 @@ def run_config(parent, cfgs, name, B, L, pos, x, av, fn, g, prof, iters, sym):
             s.debug_set("cu_mask_xcd", (k * nx) % 8 + 16 * (nx - 1))
         s.debug_set("dbg_skip", av)
         s.debug_set("fuse_norm", fn)
-        s.debug_set("wide_min_streams", WM[0])
+        s.debug_set("wide_min_streams", WM[0]); s.debug_set("wide_mode", WM[1])
     ms = [0.0] * L; err = []
     gate = threading.Barrier(L)
 
@@ -75,13 +75,13 @@ def main():
     parent = cz.Session("smollm", cz.smollm2_135m_config(), seed=0x5EED, embed_std=0.02, max_streams=args.max_streams)
     for c in args.configs:
         name, _, kv = c.partition(":")
-        d = dict(B=128, L=1, pos=767, x=0, av=0, fn=0, g=1, prof=0, gt=384, mt=8, wm=256, dw=256)
+        d = dict(B=128, L=1, pos=767, x=0, av=0, fn=0, g=1, prof=0, gt=384, mt=8, wm=256, dw=256, wmode=1)
         for item in kv.split(","):
             if item:
                 k, v = item.split("=")
                 d[k] = int(v)
         parent.debug_set("dec_grid_target", d["gt"]); parent.debug_set("dec_mt_max", d["mt"])     # (process-wide knobs)
-        WM[0] = d["wm"]; parent.debug_set("dec_wide_rows", d["dw"])
+        WM[0] = d["wm"]; WM[1] = d["wmode"]; parent.debug_set("dec_wide_rows", d["dw"])
         run_config(parent, None, name + f"[gt={d['gt']}]", d["B"], d["L"], d["pos"], d["x"], d["av"], d["fn"], d["g"], d["prof"], args.iters, args.sym)
     parent.close()
 
