@@ -11,7 +11,8 @@ generation being compressed (cz_encode_tokens_range_batch; the serial arithmetic
 the lock-step decompress of window w of the generation whose payloads are complete (cz_decode_advance: KV cache, arithmetic-decoder
 state and decoded ids stay in HBM between steps).  Both generations are full 17 408-token samples, so the re-prime sawtooth every
 step sees is the steady-state one whatever K is: 17 408 / window steps are exactly one 64 KiB sample per stream, and any other K times the
-same configuration (with the default 256-token window and re-prime interval 512, every second step holds a re-prime).  Every generation's round trip is verified when its last window has been decoded.  Pipeline fill (the compress
+same configuration (the window is a multiple of the re-prime interval: a smaller one would re-compute the 511 history rows of a segment
+once per window).  Every generation's round trip is verified when its last window has been decoded.  Pipeline fill (the compress
 of generation 0) happens before the warmup steps and is not timed.
 
 Contract line (rank 0): metric/value/unit/n_gpus/steps/warmup/ms_per_step/... + "roofline" (the kernel FUNCTION with the largest
@@ -202,13 +203,13 @@ def cpu_baseline(sample_tokens, context, reprime):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=17, help="timed steps; 68 windows of 256 tokens are one 64 KiB sample per stream")
+    ap.add_argument("--steps", type=int, default=17, help="timed steps; 34 windows of 512 tokens are one 64 KiB sample per stream")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=1024, help="streams (64 KiB chunks) per GPU, decoded in lock-step (KV cache: 94 MB per stream)")
+    ap.add_argument("--streams", type=int, default=768, help="streams (64 KiB chunks) per GPU, decoded in lock-step (KV cache: 94 MB per stream)")
     ap.add_argument("--lanes", type=int, default=2, help="concurrent lock-step decode groups per GPU (library decode lanes)")
-    ap.add_argument("--lane-streams", type=int, default=512, help="streams per lock-step group (>= 256: the wide-group decode step)")
+    ap.add_argument("--lane-streams", type=int, default=384, help="streams per lock-step group (>= 256: the wide-group decode step)")
     ap.add_argument("--sample-tokens", type=int, default=17408, help="tokens per stream (a 64 KiB enwik8 sample is ~17.4k SmolLM2 tokens)")
-    ap.add_argument("--window", type=int, default=256, help="tokens per stream and step")
+    ap.add_argument("--window", type=int, default=512, help="tokens per stream and step; a multiple of the re-prime interval, so that no window re-computes another one's history rows")
     ap.add_argument("--no-graph", action="store_true", help="launch the decode step eagerly (one AQL packet per submission: for rocprofv3 --pmc)")
     ap.add_argument("--no-events", action="store_true", help="no HIP-event timing inside the timed region (for rocprofv3 --pmc)")
     ap.add_argument("--step-sync", action="store_true", help="with --no-graph: synchronise after every decode step, so that launches never queue up (rocprofv3 --pmc, DESIGN.md §9)")

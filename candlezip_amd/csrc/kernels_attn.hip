@@ -320,12 +320,17 @@ __global__ __launch_bounds__(256, (REP * NI <= 48 ? 2 : 1)) void attention_v2_ke
                     Et[(rt * 16 + qr) * V2_KS + wave * 16 + li] = e;
                 }
             __syncthreads();
-            if (tid < REP * 16) {
-                const float* p = Et + tid * V2_KS;
-                float acc = 0.0f;
-#pragma unroll 16
-                for (int k = 0; k < 64; ++k) acc = acc + p[k];
-                csum[tid][c] = acc;
+            if (wave < REP) {
+                // canonical chunk sum of head `wave`'s 16 rows (acc = acc + e_k, k ascending from 0) on the MFMA: with B = 1 the chain
+                // fma(e_k, 1, acc) rounds e_k + acc once — the same bits as the add — and sixteen 16x16x4 steps replace 64 dependent LDS reads + adds
+                const float* pa = Et + (wave * 16 + li) * V2_KS + lg;            // A[i = li][k = 4t + lg] = e[row][key]
+                f32x4 sacc = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 16; ++t) sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * t], 1.0f, sacc, 0, 0, 0);
+                if (li == 0) {                                                    // C/D: row = 4*lg + r; every column holds the same sum
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) csum[wave * 16 + 4 * lg + r][c] = sacc[r];
+                }
             }
             __syncthreads();
         }

@@ -54,3 +54,26 @@ def test_single_file_encode_sharded_over_two_ranks_writes_the_same_canz(tmp_path
     assert one.read_bytes() == two.read_bytes()
     _ranks(2, [*base, "decompress", str(two), str(back)], 28611 + os.getpid() % 500)   # rank 0 decodes the single stream
     assert np.array_equal(np.fromfile(back, "<u4"), ids)
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py's N > 1 path (work list -> LPT share per rank, barrier, max-over-ranks timing, one JSON line from rank 0) with two gloo ranks
+    on GPU 0 and the tiny model; the driver runs the RCCL / multi-GPU case"""
+    argv = ["bench.py", "--gpus", "2", "--tiny", "--streams", "6", "--lanes", "2", "--lane-streams", "3", "--sample-tokens", "1536", "--window", "512",
+            "--steps", "3", "--warmup", "1", "--profile-tokens", "64", "--cpu-sample", "0"]
+    procs = []
+    port = 27611 + os.getpid() % 500
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   CZ_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, *argv], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-3000:]
+        outs.append(out)
+    line = json.loads(outs[0].strip().splitlines()[-1])
+    assert outs[1].strip() == ""                                   # only rank 0 prints
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["generations_verified"] >= 1                       # 3 windows of 512 = one whole 1536-token sample: round trip checked
+    assert "roofline" in line and line["config"]["streams_per_gpu"] == 6
