@@ -442,14 +442,14 @@ hipError_t cz_launch_dec_gemm_swiglu(hipStream_t st, const float* A, int lda, co
 // Wave w owns key chunks w, w+8, ... through all phases (scores stay in registers), so only three block barriers are
 // needed: after the local maxima, after the chunk sums, after the chunk partials of P.V.
 // HBM-bound: algorithmic bytes = 2 * nk * 256 B per block (K and V rows of the group's kv head, f32).
-#define DA_THREADS 512
-#define DA_WAVES (DA_THREADS / 64)
 #define DA_MAXREP 4
-#define DA_MAXC 4                                 // chunks per wave: 8 * 4 * 64 = 2048 keys
+#define DA_MAXW 16                                // most waves per block (LDS sizing of the per-wave maxima)
 typedef __attribute__((address_space(1))) const float gfloat;     // K/V pointers come out of a descriptor in memory: tell the
                                                                   // compiler they are global (global_load, not flat_load)
-template <int rep>   // query heads per kv head: compile-time so that the per-head code carries no branches
-__global__ __launch_bounds__(DA_THREADS, 4) void dec_attn_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
+// rep = query heads per kv head (compile-time so that the per-head code carries no branches); DA_WAVES = 8 waves per block for whole-device
+// grids, 16 where the grid is small (a single stream has n_kv blocks in all: twice the waves halve the chunks each wave walks serially)
+template <int rep, int DA_WAVES>
+__global__ __launch_bounds__(DA_WAVES * 64, 4) void dec_attn_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
                                                               const cz_seq_desc* __restrict__ descs, int n_heads, int n_kv, int s_stride,
                                                               size_t kv_off, const int* __restrict__ pos_dev, int out_kq) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -466,7 +466,8 @@ __global__ __launch_bounds__(DA_THREADS, 4) void dec_attn_kernel(const float* __
     float* S = qs + rep * 64;                           // [rep][s_stride]  e, then p
     float* part = S + rep * s_stride;                   // [nch_max][rep][64]   chunk partials of P.V
     float* red = part + nch_max * rep * 64;             // [DA_WAVES][DA_MAXREP] local maxima
-    float* csum = red + DA_WAVES * DA_MAXREP;           // [rep][32]       chunk sums of e
+    float* csum = red + DA_MAXW * DA_MAXREP;            // [rep][32]       chunk sums of e
+    constexpr int DA_MAXC = 32 / DA_WAVES;              // chunks per wave: 32 chunks = 2048 keys per block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < rep * 64) qs[tid] = Q[(size_t)sd.row0 * ldq + (kvh * rep + (tid >> 6)) * 64 + (tid & 63)];
     __syncthreads();
@@ -617,27 +618,43 @@ __global__ __launch_bounds__(DA_THREADS, 4) void dec_attn_kernel(const float* __
 static int da_s_stride(int max_nk) { return ((max_nk + 63) / 64) * 64 + 4; }
 static size_t da_smem(int max_nk, int rep) {
     const int nch = (max_nk + 63) / 64;
-    return (size_t)(rep * 64 + rep * da_s_stride(max_nk) + nch * rep * 64 + DA_WAVES * DA_MAXREP + rep * 32) * sizeof(float);
+    return (size_t)(rep * 64 + rep * da_s_stride(max_nk) + nch * rep * 64 + DA_MAXW * DA_MAXREP + rep * 32) * sizeof(float);
+}
+template <int rep, int W>
+static hipError_t da_prepare(int max_nk) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<rep, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk, rep));
 }
 hipError_t cz_dec_attn_prepare(int max_nk) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk, 1));
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk, 2));
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk, 3));
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk, 4));
+    hipError_t e = da_prepare<1, 8>(max_nk);
+    if (e == hipSuccess) e = da_prepare<2, 8>(max_nk);
+    if (e == hipSuccess) e = da_prepare<3, 8>(max_nk);
+    if (e == hipSuccess) e = da_prepare<4, 8>(max_nk);
+    if (e == hipSuccess) e = da_prepare<1, 16>(max_nk);
+    if (e == hipSuccess) e = da_prepare<2, 16>(max_nk);
+    if (e == hipSuccess) e = da_prepare<3, 16>(max_nk);
+    if (e == hipSuccess) e = da_prepare<4, 16>(max_nk);
     return e;
+}
+int g_dec_attn_small_grid = 128;   // tuning knob (cz_debug_set "dec_attn_small_grid"): grids of at most this many blocks run 16 waves per block
+template <int W>
+static void da_launch(hipStream_t st, int rep, dim3 grid, size_t smem, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs,
+                      int n_heads, int n_kv, int ss, size_t kv_off, const int* pos_dev, int out_kq) {
+    const dim3 block(W * 64);
+    switch (rep) {
+        case 1: hipLaunchKernelGGL((dec_attn_kernel<1, W>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;
+        case 2: hipLaunchKernelGGL((dec_attn_kernel<2, W>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;
+        case 3: hipLaunchKernelGGL((dec_attn_kernel<3, W>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;
+        default: hipLaunchKernelGGL((dec_attn_kernel<4, W>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;
+    }
 }
 hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nstreams, int max_nk,
                               int n_heads, int n_kv, size_t kv_off, const int* pos_dev, int out_kq) {
     if (nstreams <= 0) return hipSuccess;
     const int rep = n_heads / n_kv;
     if (rep < 1 || rep > DA_MAXREP || max_nk > 2048) return hipErrorInvalidValue;
-    const dim3 grid(nstreams, n_kv), block(DA_THREADS);
+    const dim3 grid(nstreams, n_kv);
     const size_t smem = da_smem(max_nk, rep); const int ss = da_s_stride(max_nk);
-    switch (rep) {
-        case 1: hipLaunchKernelGGL(dec_attn_kernel<1>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;
-        case 2: hipLaunchKernelGGL(dec_attn_kernel<2>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;
-        case 3: hipLaunchKernelGGL(dec_attn_kernel<3>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;
-        default: hipLaunchKernelGGL(dec_attn_kernel<4>, grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;
-    }
+    if (nstreams * n_kv <= g_dec_attn_small_grid) da_launch<16>(st, rep, grid, smem, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq);
+    else da_launch<8>(st, rep, grid, smem, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq);
     return hipGetLastError();
 }

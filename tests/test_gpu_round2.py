@@ -183,6 +183,7 @@ def test_wide_group_step_is_bitexact(cz, czo, shape, path):
         gcfg, ocfg, V, n_tok, seed = cz.smollm2_135m_config(), czo.smollm2_135m_config(), 49152, 40, 0x5EED
     g = cz.Session("smollm", gcfg, seed=seed, embed_std=0.05 if shape == "tiny" else 0.02, max_streams=6)
     o = czo.SmolLmSession(ocfg, seed=seed, embed_std=0.05 if shape == "tiny" else 0.02)
+    g.debug_set("dec_attn_small_grid", 0 if path in ("tiled", "np2") else 128)   # decode attention with 8 waves per block (whole-device grids) / 16 (small grids)
     if path == "tiled":
         g.debug_set("wide_min_streams", 1)                                # every group, even one stream, takes the tiled-GEMM step
     elif path == "mid":                                                   # the K-group GEMM (kernels_gemm_mid.hip) for the four layer projections
@@ -213,5 +214,5 @@ def test_wide_group_step_is_bitexact(cz, czo, shape, path):
         for s_, out, (_, z) in zip(streams, outs, coded):
             if z == 0:
                 assert np.array_equal(out, s_)
-    g.debug_set("dec_wide_rows", 256)
+    g.debug_set("dec_wide_rows", 256); g.debug_set("dec_attn_small_grid", 128)
     g.close(); o.close()
