@@ -392,7 +392,8 @@ static cz_status llama_step_fast(cz_session* s, int B, int pos, int max_nk) {
         }
         if (s->dbg_skip & 2) continue;
         s->prof_begin(PK_DEC_GEMM); HIPCHK(cz_launch_dec_gemm_plain(st, att, d, dec(y.wo), x, d, x, B, d, d, nullptr, 0.0f)); s->prof_end(2.0 * B * (double)d * d, (double)d * d * 2);
-        if (s->fuse_norm && cz_dec_gemm_norm_is_cheap(d)) {       // RMSNorm(ln2) inside the gate|up projection: sum of squares on the MFMA, x read once per block
+        if ((s->fuse_norm || B <= 16) && cz_dec_gemm_norm_is_cheap(d)) {   // RMSNorm(ln2) inside the gate|up projection (sum of squares on the MFMA): one launch less per
+                                                                          // layer; pays for one row tile (a single stream: -3 % per step), loses from 128 rows on (+17 us per layer)
             s->prof_begin(PK_DEC_GEMM_GU); HIPCHK(cz_launch_dec_gemm_swiglu(st, x, d, dec(y.wgu), h, f, B, f, d, y.ln2, c.rms_eps)); s->prof_end(4.0 * B * (double)f * d, (double)f * d * 4);
         } else {                                                   // many column blocks would each repeat a pass over their rows: normalise once
             s->prof_begin(PK_DEC_NORM); HIPCHK(cz_launch_dec_rmsnorm(st, x, d, y.ln2, xn, d, B, d, c.rms_eps)); s->prof_end(0, (double)B * d * 8);

@@ -73,7 +73,7 @@ def test_bench_two_ranks_rehearsal():
         assert p.returncode == 0, err[-3000:]
         outs.append(out)
     line = json.loads(outs[0].strip().splitlines()[-1])
-    assert outs[1].strip() == ""                                   # only rank 0 prints
+    assert not any(l.startswith("{") for l in outs[1].splitlines())           # only rank 0 prints the line (gloo itself may chat on stdout)
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
     assert line["generations_verified"] >= 1                       # 3 windows of 512 = one whole 1536-token sample: round trip checked
     assert "roofline" in line and line["config"]["streams_per_gpu"] == 6

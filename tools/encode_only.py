@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Tuning aid: segment-parallel encode only (no decode), SmolLM2-135M shape: `streams` streams x `tokens` tokens; prints tokens/s and the
+per-family HIP-event split.  Used under rocprofv3 (--pmc / --kernel-trace) to look at the big-M GEMM and the prefill attention alone."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import candlezip_amd as cz
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+s = cz.Session("smollm", cz.smollm2_135m_config(), seed=0x5EED, embed_std=0.02, max_streams=1)
+rng = np.random.default_rng(3)
+streams = [np.concatenate([[0], rng.integers(0, 49152, T)]).astype(np.uint32) for _ in range(B)]
+s.encode_tokens_batch(streams[:8])            # page the code in
+s.profile_enable(True)
+t0 = time.perf_counter()
+for _ in range(reps):
+    s.encode_tokens_batch(streams)
+dt = time.perf_counter() - t0
+prof = s.profile_read()
+print(json.dumps({"streams": B, "tokens": T, "compress_tokens_per_s": round(reps * B * T / dt, 1),
+                  "families_ms": {k: round(v["total_ms"], 1) for k, v in prof.items()},
+                  "gemm_tflops": round(sum(v["flops"] for k, v in prof.items() if k.startswith("gemm")) / max(sum(v["total_ms"] for k, v in prof.items() if k.startswith("gemm")), 1e-9) / 1e9, 1),
+                  "attention_tflops": round(prof.get("attention_f32_mfma", {"flops": 0})["flops"] / max(prof.get("attention_f32_mfma", {"total_ms": 1e-9})["total_ms"], 1e-9) / 1e9, 1)}))
+s.close()
