@@ -324,6 +324,9 @@ cz_status cz_rwkv7_build(cz_session* s, const cz_model_desc* desc) {
         CZCHK(fetch(name, tmp, (size_t)N * K, stdv, 0.0f));
         hipLaunchKernelGGL(rw_pack_kernel, dim3(1024), dim3(256), 0, s->stream, tmp, *out, (size_t)N, K, Kp);
         HIPCHK(hipGetLastError());
+        // `tmp` is reused by the next matrix.  Synthetic tensors are generated on s->stream (ordered behind this kernel), but a checkpoint
+        // tensor arrives by a blocking hipMemcpy on the null stream, which a non-blocking stream does not wait for: drain the pack first
+        if (!synthetic) HIPCHK(hipStreamSynchronize(s->stream));
         return CZ_OK;
     };
     auto vec = [&](const std::string& name, uint16_t** out, int n, float stdv, float mean) -> cz_status {

@@ -9,6 +9,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 s = cz.Session("smollm", cz.smollm2_135m_config(), seed=0x5EED, embed_std=0.02, max_streams=1)
+if len(sys.argv) > 4:
+    s.debug_set("attn_v1", int(sys.argv[4]))      # 0 = attention_v2 (default), 1 = the LDS-resident v1 kernel
 rng = np.random.default_rng(3)
 streams = [np.concatenate([[0], rng.integers(0, 49152, T)]).astype(np.uint32) for _ in range(B)]
 s.encode_tokens_batch(streams[:8])            # page the code in
