@@ -6,14 +6,14 @@ reprime 512: per GPU `--streams` persistent streams of `--sample-tokens` tokens 
 No checkpoint / tokenizer / enwik8 exists offline, so weights are seeded synthetic bf16 tensors and ids are uniform random:
 throughput and roofline are meaningful, bits/byte is not (reported as null).
 
-One "step" = one `--window`-token slice of the self-test of EVERY stream: the segment-parallel compress of window w of the
-generation being compressed (cz_encode_tokens_range_batch; the serial arithmetic coder runs when the generation is complete) and
-the lock-step decompress of window w of the generation whose payloads are complete (cz_decode_advance: KV cache, arithmetic-decoder
-state and decoded ids stay in HBM between steps).  Both generations are full 17 408-token samples, so the re-prime sawtooth every
-step sees is the steady-state one whatever K is: 17 408 / window steps are exactly one 64 KiB sample per stream, and any other K times the
-same configuration (the window is a multiple of the re-prime interval: a smaller one would re-compute the 511 history rows of a segment
-once per window).  Every generation's round trip is verified when its last window has been decoded.  Pipeline fill (the compress
-of generation 0) happens before the warmup steps and is not timed.
+One "step" = one `--window`-token slice of the self-test of EVERY stream, as a two-stage pipeline on the same persistent streams: the
+segment-parallel compress of the next window of the compress stage (cz_encode_tokens_range_batch + the serial arithmetic coder fed window
+by window) and the lock-step decompress of the next window of the decompress stage, which runs two windows behind and is fed the coder's
+bytes as they become final (cz_decode_feed_batch / cz_decode_advance: KV cache, arithmetic-decoder state and decoded ids stay in HBM
+between steps).  Streams are whole 17 408-token samples, so the re-prime sawtooth every step sees is the steady-state one whatever K is:
+17 408 / window steps are exactly one 64 KiB sample per stream, and any other K times the same configuration (the window is a multiple of
+the re-prime interval: a smaller one would re-compute the 511 history rows of a segment once per window).  Every sample's round trip is
+verified when its last window has been decoded.  Pipeline fill (two windows of compress) happens before the warmup steps and is not timed.
 
 Contract line (rank 0): metric/value/unit/n_gpus/steps/warmup/ms_per_step/... + "roofline" (the kernel FUNCTION with the largest
 total time, all its instantiations summed; HIP-event timed on the library's stream in an eager pass inside this script) +
@@ -82,89 +82,125 @@ def pmc_traffic(prefix, tokens=1536):
 
 
 class Generation:
-    """one 64 KiB sample per stream: ids, the coder intervals collected window by window, then the payloads"""
+    """one 64 KiB sample per stream: ids, one incremental arithmetic encoder per stream, the payload bytes not yet handed to the decoder"""
 
-    def __init__(self, stream_ids, gen, n_tokens, vocab):
+    def __init__(self, cz, stream_ids, gen, n_tokens, vocab):
         self.ids = []
         for sid in stream_ids:                                   # seeded by the GLOBAL stream id: the work list is the same for any rank count
             rng = np.random.default_rng([1000 + sid, gen])
             self.ids.append(np.concatenate([[0], rng.integers(0, vocab, n_tokens)]).astype(np.uint32))
-        self.lo = [np.zeros(n_tokens, np.uint32) for _ in stream_ids]
-        self.hi = [np.zeros(n_tokens, np.uint32) for _ in stream_ids]
-        self.payloads = None
+        self.encs = [cz.AcEncoder() for _ in stream_ids]
+        self.pending = [b"" for _ in stream_ids]
+        self.complete = False
+        self.bytes = 0
+
+    def take(self):
+        out, self.pending = self.pending, [b"" for _ in self.pending]
+        return out
 
 
 class SelfTestPipeline:
-    def __init__(self, cz, sess, stream_ids, n_tokens, window, vocab, context, reprime):
+    """The self-test of persistent streams as a two-stage pipeline over 512-token windows: the compress stage runs LAG windows ahead of the
+    decompress stage ON THE SAME STREAMS; the arithmetic coder's bytes are fed to the device decoder as they become final
+    (cz_ac_encoder_push -> cz_decode_feed_batch), exactly as a decompressor reading a file that is still being written would see them."""
+    LAG = 2
+
+    def __init__(self, cz, sess, stream_ids, n_tokens, window, vocab, context, reprime, enc_sess=None):
         self.cz, self.sess, self.sids, self.T, self.W, self.V = cz, sess, stream_ids, n_tokens, window, vocab
+        self.enc_sess = enc_sess      # a fork of the session (own HIP stream, same weights): the compress half then runs WHILE the decompress half does
         self.ctx, self.R = context, reprime
         self.nwin = -(-n_tokens // window)
-        self.gen_no = 0
-        self.dec = None; self.enc = None; self.w = 0
+        self.gens = {}
+        self.cg = self.cw = self.dg = self.dw = 0                # compress / decompress cursors: (generation, window)
         self.te = self.td = 0.0; self.tok = 0; self.bytes = 0; self.verified = 0
 
     def _window(self, w):
         return w * self.W, min((w + 1) * self.W, self.T)
 
-    def _compress_window(self, g, w):
+    def _gen(self, g):
+        if g not in self.gens:
+            self.gens[g] = Generation(self.cz, self.sids, g, self.T, self.V)
+        return self.gens[g]
+
+    def _compress_next(self):
+        g, w = self._gen(self.cg), self.cw
         b, e = self._window(w)
         t = time.perf_counter()
-        parts = self.sess.encode_tokens_range_batch(g.ids, [(b, e)] * len(g.ids), self.ctx, self.R)
-        for k, (lo, hi) in enumerate(parts):
-            g.lo[k][b:e] = lo; g.hi[k][b:e] = hi
-        if w == self.nwin - 1:                                   # ArithmeticEncoder over the whole stream (src/main.rs:2300, 2358)
-            g.payloads = [self.cz.ac_encode_pairs(lo, hi)[0] for lo, hi in zip(g.lo, g.hi)]
-            g.lo = g.hi = None
+        parts = (self.enc_sess or self.sess).encode_tokens_range_batch(g.ids, [(b, e)] * len(g.ids), self.ctx, self.R)
+        last = w == self.nwin - 1
+        for k, (lo, hi) in enumerate(parts):                     # ArithmeticEncoder::encode_counts, window by window (src/main.rs:2300); finish (:2358)
+            nb = g.encs[k].push(lo, hi)
+            if last:
+                nb += g.encs[k].finish()[0]
+                g.encs[k].close()
+            g.pending[k] += nb
+            g.bytes += len(nb)
+        g.complete = g.complete or last
+        self.cw += 1
+        if self.cw == self.nwin:
+            self.cg += 1; self.cw = 0
         return time.perf_counter() - t
 
-    def _new_gen(self):
-        g = Generation(self.sids, self.gen_no, self.T, self.V)
-        self.gen_no += 1
-        return g
+    def _begin_decode(self):
+        g = self._gen(self.dg)
+        self.sess.decode_begin_partial_batch(g.take(), [4 * self.T + 64] * len(self.sids), [self.T] * len(self.sids), self.ctx, self.R, 0)
+        self._fed_final = False
+
+    def _feed(self):
+        g = self._gen(self.dg)
+        if not self._fed_final and (any(g.pending) or g.complete):
+            self.sess.decode_feed_batch(g.take(), final=g.complete)
+            self._fed_final = g.complete
 
     def fill(self):
-        """untimed: compress generation 0 completely, open its decode, start generation 1"""
-        g = self._new_gen()
-        for w in range(self.nwin):
-            self._compress_window(g, w)
-        self.dec = g
-        self.sess.decode_begin_batch(g.payloads, [self.T] * len(self.sids), self.ctx, self.R, 0)
-        self.enc = self._new_gen()
-        self.w = 0
+        """untimed: the compress stage gets LAG windows ahead, the decode of generation 0 is opened"""
+        for _ in range(self.LAG):
+            self._compress_next()
+        self._begin_decode()
 
     def _check(self, upto):
-        outs = self.sess.decode_fetch_batch()
-        for s, o in zip(self.dec.ids, outs):
+        outs = self.sess.decode_fetch_batch()                    # (raises if a decoder ran past the bytes fed so far)
+        for s, o in zip(self._gen(self.dg).ids, outs):
             if not np.array_equal(s[: upto + 1], o[: upto + 1]):
                 raise RuntimeError("self-test round trip mismatch")
 
     def step(self):
-        """compress window w of the generation being compressed + decompress window w of the one being decompressed"""
-        b, e = self._window(self.w)
-        self.te += self._compress_window(self.enc, self.w)
-        t = time.perf_counter()
-        self.sess.decode_advance(e - b)
-        self.td += time.perf_counter() - t
+        """compress the next window of the compress stage + decompress the next window of the decompress stage"""
+        b, e = self._window(self.dw)
+        if self.enc_sess is not None:                            # two jobs share the device: MFMA-bound compress beside the HBM-bound decompress
+            import threading
+            self._feed()
+            box = {}
+            th = threading.Thread(target=lambda: box.__setitem__("te", self._compress_next()))
+            th.start()
+            t = time.perf_counter()
+            self.sess.decode_advance(e - b)
+            self.td += time.perf_counter() - t
+            th.join()
+            self.te += box["te"]
+        else:
+            self.te += self._compress_next()
+            t = time.perf_counter()
+            self._feed()
+            self.sess.decode_advance(e - b)
+            self.td += time.perf_counter() - t
         self.tok += (e - b) * len(self.sids)
-        self.w += 1
-        if self.w == self.nwin:                                  # generation complete: verify, rotate
+        self.dw += 1
+        if self.dw == self.nwin:                                 # generation complete: verify, move on to the next one
             t = time.perf_counter()
             self._check(self.T)
             self.verified += 1
-            self.bytes += sum(len(p) for p in self.dec.payloads)
+            self.bytes += self._gen(self.dg).bytes
             self.sess.decode_end()
-            self.dec = self.enc
-            self.sess.decode_begin_batch(self.dec.payloads, [self.T] * len(self.sids), self.ctx, self.R, 0)
+            del self.gens[self.dg]
+            self.dg += 1; self.dw = 0
+            self._begin_decode()
             self.td += time.perf_counter() - t
-            self.enc = self._new_gen()
-            self.w = 0
 
     def finish(self):
         """verify what has been decoded of the generation in flight, release the slot"""
-        if self.dec is not None:
-            self._check(self._window(self.w)[0] if self.w else 0)
-            self.sess.decode_end()
-            self.dec = None
+        self._check(self._window(self.dw)[0] if self.dw else 0)
+        self.sess.decode_end()
 
 
 def self_test_step(cz, sess, streams, context, reprime):
@@ -205,11 +241,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=17, help="timed steps; 34 windows of 512 tokens are one 64 KiB sample per stream")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=768, help="streams (64 KiB chunks) per GPU, decoded in lock-step (KV cache: 94 MB per stream)")
+    ap.add_argument("--streams", type=int, default=1024, help="streams (64 KiB chunks) per GPU, decoded in lock-step (KV cache: 94 MB per stream)")
     ap.add_argument("--lanes", type=int, default=2, help="concurrent lock-step decode groups per GPU (library decode lanes)")
-    ap.add_argument("--lane-streams", type=int, default=384, help="streams per lock-step group (>= 256: the wide-group decode step)")
+    ap.add_argument("--lane-streams", type=int, default=512, help="streams per lock-step group (>= 256: the wide-group decode step)")
     ap.add_argument("--sample-tokens", type=int, default=17408, help="tokens per stream (a 64 KiB enwik8 sample is ~17.4k SmolLM2 tokens)")
     ap.add_argument("--window", type=int, default=512, help="tokens per stream and step; a multiple of the re-prime interval, so that no window re-computes another one's history rows")
+    ap.add_argument("--overlap", type=int, default=0, help="1: the compress half of a step runs on a forked session WHILE the decompress half runs")
     ap.add_argument("--no-graph", action="store_true", help="launch the decode step eagerly (one AQL packet per submission: for rocprofv3 --pmc)")
     ap.add_argument("--no-events", action="store_true", help="no HIP-event timing inside the timed region (for rocprofv3 --pmc)")
     ap.add_argument("--step-sync", action="store_true", help="with --no-graph: synchronise after every decode step, so that launches never queue up (rocprofv3 --pmc, DESIGN.md §9)")
@@ -254,7 +291,8 @@ def main():
         sess.debug_set(k, int(v))
     # work list: world x streams independent files; LPT over the ranks (equal sizes -> `streams` per rank), no data-path collective
     mine = lpt_assign([args.sample_tokens] * (world * args.streams), world)[rank]
-    pipe = SelfTestPipeline(cz, sess, mine, args.sample_tokens, args.window, cfg.vocab, args.context, args.reprime_interval)
+    enc_sess = sess.fork() if args.overlap else None
+    pipe = SelfTestPipeline(cz, sess, mine, args.sample_tokens, args.window, cfg.vocab, args.context, args.reprime_interval, enc_sess)
     note(f"rank {rank}/{world}: session open, {len(mine)} streams x {args.sample_tokens} tokens, {groups} lanes x {per_lane}, window {args.window}")
     if os.environ.get("CZ_DUMP_MAPS"):      # diagnostics: the address map of this process (to symbolise a native stack trace afterwards)
         import shutil
@@ -267,8 +305,8 @@ def main():
         torch.cuda.synchronize()
 
     sess.profile_enable(False)
-    pipe.fill()                                                           # untimed: generation 0 compressed, its decode opened
-    note("pipeline filled (generation 0 compressed)")
+    pipe.fill()                                                           # untimed: the compress stage two windows ahead, the decode opened
+    note("pipeline filled (compress stage two windows ahead)")
     for _ in range(args.warmup):                                          # W untimed steps of the same pipeline (first one builds the decode hipGraphs)
         pipe.step()
     pipe.te = pipe.td = 0.0; pipe.tok = 0
@@ -350,11 +388,11 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"enwik8 64 KiB samples, chunk-sharded: {args.streams} persistent streams x {args.sample_tokens} tokens per GPU, one step = a "
-                                   f"{args.window}-token window of every stream (compress of the generation being written + decompress of the generation being "
-                                   f"read; {pipe.nwin} steps = one whole sample), SmolLM2-135M shape ({'tiny test model' if args.tiny else 'd576 L30 9q/3kv ffn1536 V49152'}), "
+                                   f"{args.window}-token window of every stream (compress stage two windows ahead of the decompress stage, coder bytes fed as they "
+                                   f"become final; {pipe.nwin} steps = one whole sample), SmolLM2-135M shape ({'tiny test model' if args.tiny else 'd576 L30 9q/3kv ffn1536 V49152'}), "
                                    f"context {args.context}, reprime_interval {args.reprime_interval}, seeded synthetic weights",
                        "streams_per_gpu": args.streams, "decode_lanes": groups, "streams_per_lane": per_lane, "tokens_per_stream": args.sample_tokens,
-                       "window_tokens": args.window, "parallelism": f"files x{world} (LPT work list, no data-path collective)"},
+                       "window_tokens": args.window, "compress_beside_decompress": bool(args.overlap), "parallelism": f"files x{world} (LPT work list, no data-path collective)"},
             "bits_per_byte": None,
             "bits_per_token_synthetic": round(8.0 * pipe.bytes / max(pipe.verified * len(mine) * args.sample_tokens, 1), 3) if pipe.verified else None,
             "generations_verified": pipe.verified,
@@ -373,6 +411,8 @@ def main():
         if world == 1 and args.cpu_sample > 0 and not args.tiny:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.context, args.reprime_interval)
         print(json.dumps(line), flush=True)
+    if enc_sess is not None:
+        enc_sess.close()
     sess.close()
     if dist is not None:
         dist.barrier()

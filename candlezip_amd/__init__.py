@@ -71,7 +71,8 @@ def tiny_rwkv7_config(vocab=512, hidden=128, n_layers=2, d_ffn=512):
 EXPORTS = [  # every symbol include/candlezip.h declares
     "cz_session_open", "cz_session_close", "cz_session_fork", "cz_vocab_size", "cz_max_context_length", "cz_index_pos", "cz_step_logits",
     "cz_reprime_logits", "cz_encode_tokens", "cz_encode_tokens_batch", "cz_encode_tokens_range_batch", "cz_decode_tokens", "cz_decode_tokens_batch",
-    "cz_decode_begin_batch", "cz_decode_advance", "cz_decode_fetch_batch", "cz_decode_end",
+    "cz_decode_begin_batch", "cz_decode_begin_partial_batch", "cz_decode_feed_batch", "cz_decode_advance", "cz_decode_fetch_batch", "cz_decode_end",
+    "cz_ac_encoder_new", "cz_ac_encoder_push", "cz_ac_encoder_finish", "cz_ac_encoder_free",
     "cz_ac_encode_pairs", "cz_free", "cz_write_header_v2", "cz_read_header_v2", "cz_flags_pack", "cz_skip_gate_section",
     "cz_blake3_bytes_bin16", "cz_blake3_file_bin16", "cz_blake3_files_bin16", "cz_rwkv_tokenizer_open",
     "cz_rwkv_tokenizer_close", "cz_rwkv_plan_symbols", "cz_rwkv_detok", "cz_bpe_tokenizer_open", "cz_bpe_tokenizer_close",
@@ -100,6 +101,11 @@ def lib():
         "cz_encode_tokens_batch": (C.c_int, [vp, sz, vp, vp, u32, u32, vp, vp]),
         "cz_encode_tokens_range_batch": (C.c_int, [vp, sz, vp, vp, u32, u32, vp, vp, vp, vp]),
         "cz_decode_begin_batch": (C.c_int, [vp, sz, vp, vp, vp, u32, u32, u32]),
+        "cz_decode_begin_partial_batch": (C.c_int, [vp, sz, vp, vp, vp, vp, u32, u32, u32]),
+        "cz_decode_feed_batch": (C.c_int, [vp, sz, vp, vp, C.c_int]),
+        "cz_ac_encoder_new": (C.c_int, [C.POINTER(vp)]), "cz_ac_encoder_free": (None, [vp]),
+        "cz_ac_encoder_push": (C.c_int, [vp, vp, vp, sz, C.POINTER(vp), C.POINTER(sz)]),
+        "cz_ac_encoder_finish": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(u64)]),
         "cz_decode_advance": (C.c_int, [vp, sz, C.POINTER(sz), C.POINTER(sz)]),
         "cz_decode_fetch_batch": (C.c_int, [vp, sz, vp]), "cz_decode_end": (C.c_int, [vp]),
         "cz_decode_tokens": (C.c_int, [vp, vp, sz, sz, u32, u32, u32, vp]),
@@ -253,6 +259,19 @@ class Session:
         self._run_tcs = [int(t) for t in token_counts]
         _check(lib().cz_decode_begin_batch(self.h, len(payloads), _ptr_array(bufs), _p(lens), _p(tcs), context_window, reprime_interval, bos))
 
+    def decode_begin_partial_batch(self, payloads, payload_caps, token_counts, context_window=512, reprime_interval=512, bos=0):
+        """begin with the bytes at hand; more arrive through decode_feed_batch (payload_caps = room per stream)"""
+        bufs = [np.frombuffer(bytes(p), np.uint8).copy() if len(p) else np.zeros(1, np.uint8) for p in payloads]
+        lens = np.array([len(p) for p in payloads], np.uint64)
+        caps = np.array(payload_caps, np.uint64); tcs = np.array(token_counts, np.uint64)
+        self._run_tcs = [int(t) for t in token_counts]
+        _check(lib().cz_decode_begin_partial_batch(self.h, len(payloads), _ptr_array(bufs), _p(lens), _p(caps), _p(tcs), context_window, reprime_interval, bos))
+
+    def decode_feed_batch(self, chunks, final=False):
+        bufs = [np.frombuffer(bytes(c), np.uint8).copy() if len(c) else np.zeros(1, np.uint8) for c in chunks]
+        lens = np.array([len(c) for c in chunks], np.uint64)
+        _check(lib().cz_decode_feed_batch(self.h, len(chunks), _ptr_array(bufs), _p(lens), 1 if final else 0))
+
     def decode_advance(self, n_tokens):
         """decode up to n_tokens more tokens per stream; returns (position, remaining) of the longest stream"""
         pos, rem = C.c_size_t(), C.c_size_t()
@@ -339,6 +358,32 @@ def ac_encode_pairs(c_lo, c_hi):
     data = C.string_at(pay, ln.value) if ln.value else b""
     lib().cz_free(pay)
     return data, int(zw.value)
+
+
+class AcEncoder:
+    """ArithmeticEncoder fed in pieces (cz_ac_encoder_*): push(c_lo, c_hi) -> the bytes that became final, finish() -> (last bytes, zero_width)"""
+
+    def __init__(self):
+        self.h = C.c_void_p()
+        _check(lib().cz_ac_encoder_new(C.byref(self.h)))
+
+    def push(self, c_lo, c_hi) -> bytes:
+        c_lo = np.ascontiguousarray(c_lo, np.uint32); c_hi = np.ascontiguousarray(c_hi, np.uint32)
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(lib().cz_ac_encoder_push(self.h, _p(c_lo), _p(c_hi), c_lo.size, C.byref(p), C.byref(n)))
+        return C.string_at(p, n.value) if n.value else b""
+
+    def finish(self):
+        p, n, tot, zw = C.c_void_p(), C.c_size_t(), C.c_size_t(), C.c_uint64()
+        _check(lib().cz_ac_encoder_finish(self.h, C.byref(p), C.byref(n), C.byref(tot), C.byref(zw)))
+        return (C.string_at(p, n.value) if n.value else b""), int(zw.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cz_ac_encoder_free(self.h)
+            self.h = None
+
+    __del__ = close
 
 
 def write_header(h: Header, model_file_repr: bytes) -> bytes:

@@ -65,7 +65,7 @@ __device__ inline void pdf_prepare(pdf_ctx& c, const float* l, int V, int mode) 
 #define AC_QUARTER 0x40000000ull
 
 __device__ __forceinline__ unsigned dec_get_bit(cz_dec_state& d) {          // :438-449 ; EOF reads as 1 (:432, :545)
-    if (d.byte_pos >= d.in_len) return 1u;
+    if (d.byte_pos >= d.in_len) { if (!d.final_input) d.underrun = 1u; return 1u; }
     unsigned byte = d.in[d.byte_pos];
     unsigned bit = (byte >> (7 - d.bit_pos)) & 1u;
     d.bit_pos += 1;

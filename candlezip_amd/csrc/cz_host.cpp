@@ -285,6 +285,32 @@ extern "C" cz_status cz_ac_encode_pairs(const uint32_t* c_lo, const uint32_t* c_
     return CZ_OK;
 }
 
+// the same encoder fed in pieces: bytes come out as soon as they are final (a decoder elsewhere may already consume them)
+struct cz_ac_encoder { AcEncoder e; size_t emitted = 0; bool finished = false; };
+extern "C" cz_status cz_ac_encoder_new(cz_ac_encoder** out) {
+    if (!out) { cz_set_error("cz_ac_encoder_new: null argument"); return CZ_ERR_ARG; }
+    *out = new cz_ac_encoder();
+    return CZ_OK;
+}
+extern "C" void cz_ac_encoder_free(cz_ac_encoder* enc) { delete enc; }
+extern "C" cz_status cz_ac_encoder_push(cz_ac_encoder* enc, const uint32_t* c_lo, const uint32_t* c_hi, size_t n, const uint8_t** new_bytes, size_t* new_len) {
+    if (!enc || ((!c_lo || !c_hi) && n) || !new_bytes || !new_len) { cz_set_error("cz_ac_encoder_push: null argument"); return CZ_ERR_ARG; }
+    if (enc->finished) { cz_set_error("cz_ac_encoder_push: the encoder was finished"); return CZ_ERR_STATE; }
+    for (size_t i = 0; i < n; ++i) enc->e.encode_counts(c_lo[i], c_hi[i], 1ull << 30);
+    *new_bytes = enc->e.out.data() + enc->emitted; *new_len = enc->e.out.size() - enc->emitted;
+    enc->emitted = enc->e.out.size();
+    return CZ_OK;
+}
+extern "C" cz_status cz_ac_encoder_finish(cz_ac_encoder* enc, const uint8_t** new_bytes, size_t* new_len, size_t* total_len, uint64_t* zero_width) {
+    if (!enc || !new_bytes || !new_len) { cz_set_error("cz_ac_encoder_finish: null argument"); return CZ_ERR_ARG; }
+    if (!enc->finished) { enc->e.finish(); enc->finished = true; }
+    *new_bytes = enc->e.out.data() + enc->emitted; *new_len = enc->e.out.size() - enc->emitted;
+    enc->emitted = enc->e.out.size();
+    if (total_len) *total_len = enc->e.out.size();
+    if (zero_width) *zero_width = enc->e.zero_width;
+    return CZ_OK;
+}
+
 // ------------------------------------------------------------------ container header v2 (src/main.rs:551-646)
 static size_t put_var(uint64_t v, uint8_t* o) { size_t n = 0; while (v >= 0x80) { o[n++] = (uint8_t)((v & 0x7F) | 0x80); v >>= 7; } o[n++] = (uint8_t)v; return n; }
 static size_t get_var(const uint8_t* in, size_t len, uint64_t* v) {

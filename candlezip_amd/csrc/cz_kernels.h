@@ -64,7 +64,10 @@ struct cz_dec_state {
     unsigned long long in_len;
     uint32_t* out_ids;            // out_ids[0] = bos, out_ids[i+1] = i-th decoded symbol
     unsigned long long token_count;
+    unsigned int final_input;     // 1: `in_len` bytes are the whole payload (reads past them are the reference's EOF bits = 1); 0: more bytes will be fed
+    unsigned int underrun;        // set when the decoder read past the bytes fed so far (final_input == 0): its ids are then garbage
 };
+hipError_t cz_launch_dec_feed(hipStream_t st, cz_dec_state* st_arr, int nstreams, const unsigned long long* new_len_dev, int final_input);
 hipError_t cz_launch_dec_init(hipStream_t st, cz_dec_state* st_arr, int nstreams);
 hipError_t cz_launch_decode_symbol(hipStream_t st, const float* logits, int ld, cz_dec_state* st_arr, uint32_t* sym_out, int nstreams,
                                    int vocab, int mode, unsigned long long i, unsigned* fallback_count, const unsigned long long* step_dev,

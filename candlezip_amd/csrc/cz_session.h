@@ -45,10 +45,12 @@ struct Rwkv7Model;   // rwkv7.hip
 // else (KV cache / recurrent state, arithmetic-decoder states, decoded ids, position counters) is device-resident
 struct DecRun {
     bool active = false, use_graph = false;
-    int B = 0;
+    int B = 0, max_nk = 0;
     std::vector<size_t> tcs;
     size_t max_tc = 0, i = 0, index_pos = 0, ec = 0, ids_total = 0;
     uint32_t R = 0, bos = 0;
+    bool partial = false;              // payloads arrive in pieces (cz_decode_begin_partial_batch / cz_decode_feed_batch)
+    std::vector<size_t> pay_off, pay_len, pay_cap;
 };
 
 struct cz_session {
@@ -102,8 +104,11 @@ cz_status cz_rwkv7_step_host(cz_session* s, uint32_t token, float* out_logits);
 cz_status cz_rwkv7_reprime_host(cz_session* s, const uint32_t* hist, size_t n, float* out_logits);
 cz_status cz_rwkv7_make_lane(const cz_session* parent, cz_session* child);
 cz_status cz_rwkv7_encode_group(cz_session* s, int B, const uint32_t* const* ids, const size_t* n, uint32_t* const* lo, uint32_t* const* hi);
-cz_status cz_rwkv7_decode_begin(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs, uint32_t bos);
+cz_status cz_rwkv7_decode_begin(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* caps, const size_t* tcs, uint32_t bos);
+// session.hip: payload buffer / decoder states of a lock-step group, shared by both back-ends
+cz_status cz_dec_run_setup(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* caps, const size_t* tcs);
+cz_status cz_dec_run_feed(cz_session* s, const uint8_t* const* chunks, const size_t* lens, int final_input);
+cz_status cz_dec_run_fetch(cz_session* s, uint32_t* const* out_ids);
 cz_status cz_rwkv7_decode_advance(cz_session* s, size_t n);
-cz_status cz_rwkv7_decode_fetch(cz_session* s, uint32_t* const* out_ids);
 cz_status cz_rwkv7_decode_group(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs, uint32_t bos,
                                 uint32_t* const* out_ids);

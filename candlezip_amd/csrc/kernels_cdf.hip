@@ -37,6 +37,18 @@ __global__ void dec_init_kernel(cz_dec_state* st, int n) {                  // A
     for (int k = 0; k < 32; ++k) d.code = (d.code << 1) | dec_get_bit(d);
     st[i] = d;
 }
+// more payload bytes have arrived (cz_decode_feed_batch): new length per stream, and whether the payloads are now complete
+__global__ void dec_feed_kernel(cz_dec_state* st, int n, const unsigned long long* __restrict__ new_len, int final_input) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st[i].in_len = new_len[i];
+    st[i].final_input = final_input ? 1u : 0u;
+}
+hipError_t cz_launch_dec_feed(hipStream_t s, cz_dec_state* st, int n, const unsigned long long* new_len_dev, int final_input) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(dec_feed_kernel, dim3((n + 63) / 64), dim3(64), 0, s, st, n, new_len_dev, final_input);
+    return hipGetLastError();
+}
 hipError_t cz_launch_dec_init(hipStream_t s, cz_dec_state* st, int n) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(dec_init_kernel, dim3((n + 63) / 64), dim3(64), 0, s, st, n);

@@ -147,7 +147,7 @@ extern "C" cz_status cz_debug_decode_symbols(const float* logits, int steps, int
     PCHK(hipMemcpy(dl, logits, (size_t)steps * V * 4, hipMemcpyHostToDevice));
     if (len) PCHK(hipMemcpy(dp, payload, len, hipMemcpyHostToDevice));
     memset(&hs, 0, sizeof hs);
-    hs.in = dp; hs.in_len = len; hs.out_ids = dout; hs.token_count = (unsigned long long)steps; hs.active = 1;
+    hs.in = dp; hs.in_len = len; hs.out_ids = dout; hs.token_count = (unsigned long long)steps; hs.active = 1; hs.final_input = 1;
     PCHK(hipMemcpy(dst, &hs, sizeof hs, hipMemcpyHostToDevice));
     PCHK(cz_launch_dec_init(0, dst, 1));
     for (int i = 0; i < steps; ++i) {

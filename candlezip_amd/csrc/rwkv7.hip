@@ -602,7 +602,7 @@ cz_status cz_rwkv7_encode_group(cz_session* s, int B, const uint32_t* const* ids
 }
 
 // the decode loop in slices (begin -> advance(n)* -> fetch), like the LLaMA one: recurrent state, decoder states and ids stay in HBM
-cz_status cz_rwkv7_decode_begin(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs, uint32_t bos) {
+cz_status cz_rwkv7_decode_begin(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* caps, const size_t* tcs, uint32_t bos) {
     Rwkv7Model* m = s->rwkv; const cz_rwkv7_config& c = m->cfg;
     const uint32_t V = (uint32_t)c.vocab;
     DecRun& run = s->run;
@@ -610,20 +610,7 @@ cz_status cz_rwkv7_decode_begin(cz_session* s, int B, const uint8_t* const* payl
     if (bos >= V) { cz_set_error("bos id %u >= vocab", bos); return CZ_ERR_ARG; }
     CZCHK(rw_ensure_streams(s, B));
     CZCHK(rw_reset(s));
-    size_t pay_total = 0, ids_total = 0, max_tc = 0;
-    for (int b = 0; b < B; ++b) { pay_total += lens[b] + 16; ids_total += tcs[b] + 1; max_tc = std::max(max_tc, tcs[b]); }
-    CZCHK(s->payload.ensure(pay_total)); CZCHK(s->outids.ensure(ids_total * 4)); CZCHK(s->decst.ensure(B * sizeof(cz_dec_state)));
-    std::vector<cz_dec_state> hs(B); std::vector<uint8_t> pay(pay_total, 0);
-    size_t po = 0, io = 0;
-    for (int b = 0; b < B; ++b) {
-        if (lens[b]) memcpy(pay.data() + po, payloads[b], lens[b]);
-        cz_dec_state d; memset(&d, 0, sizeof d);
-        d.in = (const uint8_t*)s->payload.p + po; d.in_len = lens[b]; d.out_ids = (uint32_t*)s->outids.p + io; d.token_count = tcs[b]; d.active = tcs[b] > 0;
-        hs[b] = d; po += lens[b] + 16; io += tcs[b] + 1;
-    }
-    HIPCHK(hipMemcpyAsync(s->payload.p, pay.data(), pay_total, hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipMemcpyAsync(s->decst.p, hs.data(), B * sizeof(cz_dec_state), hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
+    CZCHK(cz_dec_run_setup(s, B, payloads, lens, caps, tcs));
     cz_dec_state* dst = (cz_dec_state*)s->decst.p;
     HIPCHK(cz_launch_dec_init(s->stream, dst, B));
     hipLaunchKernelGGL(rw_init_out_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, dst, B, bos);
@@ -640,8 +627,7 @@ cz_status cz_rwkv7_decode_begin(cz_session* s, int B, const uint8_t* const* payl
             }));
         hipLaunchKernelGGL(rw_counter_kernel, dim3(1), dim3(1), 0, s->stream, m->step_dev, 0);
     }
-    run.B = B; run.tcs.assign(tcs, tcs + B); run.max_tc = max_tc; run.i = 0; run.index_pos = 0; run.ec = 0; run.R = 0; run.bos = bos;
-    run.ids_total = ids_total; run.use_graph = use_graph; run.active = true;
+    run.i = 0; run.index_pos = 0; run.ec = 0; run.R = 0; run.bos = bos; run.use_graph = use_graph; run.active = true;
     return CZ_OK;
 }
 cz_status cz_rwkv7_decode_advance(cz_session* s, size_t n) {
@@ -657,21 +643,11 @@ cz_status cz_rwkv7_decode_advance(cz_session* s, size_t n) {
     HIPCHK(hipStreamSynchronize(s->stream));
     return CZ_OK;
 }
-cz_status cz_rwkv7_decode_fetch(cz_session* s, uint32_t* const* out_ids) {
-    DecRun& run = s->run;
-    if (!run.active) { cz_set_error("no decode in progress on this session (cz_decode_begin_batch first)"); return CZ_ERR_STATE; }
-    std::vector<uint32_t> all(run.ids_total);
-    HIPCHK(hipMemcpyAsync(all.data(), s->outids.p, run.ids_total * 4, hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
-    size_t io = 0;
-    for (int b = 0; b < run.B; ++b) { memcpy(out_ids[b], all.data() + io, (run.tcs[b] + 1) * 4); if (run.tcs[b] == 0) out_ids[b][0] = run.bos; io += run.tcs[b] + 1; }
-    return CZ_OK;
-}
 cz_status cz_rwkv7_decode_group(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs, uint32_t bos,
                                 uint32_t* const* out_ids) {
-    CZCHK(cz_rwkv7_decode_begin(s, B, payloads, lens, tcs, bos));
+    CZCHK(cz_rwkv7_decode_begin(s, B, payloads, lens, nullptr, tcs, bos));
     cz_status rc = cz_rwkv7_decode_advance(s, s->run.max_tc);
-    if (rc == CZ_OK) rc = cz_rwkv7_decode_fetch(s, out_ids);
+    if (rc == CZ_OK) rc = cz_dec_run_fetch(s, out_ids);
     s->run.active = false;
     s->index_pos = 0;
     return rc;

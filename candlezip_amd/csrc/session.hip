@@ -761,7 +761,65 @@ static cz_status xe_llama(cz_session* s, size_t n_spans, const uint32_t* const* 
 // ------------------------------------------------------------------ decode (lock-step)
 // One lock-step group lives on one lane (session): its KV cache, arithmetic-decoder states, decoded ids and position counters stay
 // in HBM between calls, so the loop of decode_file (src/main.rs:2528-2541, 2621-2628) can be run in slices: begin -> advance(n)* -> fetch.
-static cz_status decode_llama_begin(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs,
+// shared by both back-ends: payload buffer + decoder states of a lock-step group.  caps == nullptr: the payloads are complete; else
+// stream b's buffer has room for caps[b] bytes and more arrive through dec_run_feed
+cz_status cz_dec_run_setup(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* caps, const size_t* tcs) {
+    DecRun& run = s->run;
+    size_t pay_total = 0, ids_total = 0, max_tc = 0;
+    run.pay_off.assign(B, 0); run.pay_len.assign(lens, lens + B); run.pay_cap.assign(B, 0); run.partial = caps != nullptr;
+    for (int b = 0; b < B; ++b) {
+        const size_t cap = caps ? std::max(caps[b], lens[b]) : lens[b];
+        run.pay_off[b] = pay_total; run.pay_cap[b] = cap;
+        pay_total += cap + 16; ids_total += tcs[b] + 1; max_tc = std::max(max_tc, tcs[b]);
+    }
+    CZCHK(s->payload.ensure(pay_total)); CZCHK(s->outids.ensure(ids_total * 4)); CZCHK(s->decst.ensure(B * sizeof(cz_dec_state)));
+    CZCHK(s->sym.ensure((size_t)B * 8));                                  // (new lengths of a feed)
+    std::vector<cz_dec_state> hs(B); std::vector<uint8_t> pay(pay_total, 0);
+    size_t io = 0;
+    for (int b = 0; b < B; ++b) {
+        if (lens[b]) memcpy(pay.data() + run.pay_off[b], payloads[b], lens[b]);
+        cz_dec_state d; memset(&d, 0, sizeof d);
+        d.in = (const uint8_t*)s->payload.p + run.pay_off[b]; d.in_len = lens[b]; d.out_ids = (uint32_t*)s->outids.p + io; d.token_count = tcs[b];
+        d.active = tcs[b] > 0; d.final_input = caps ? 0 : 1;
+        hs[b] = d; io += tcs[b] + 1;
+    }
+    HIPCHK(hipMemcpyAsync(s->payload.p, pay.data(), pay_total, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(s->decst.p, hs.data(), B * sizeof(cz_dec_state), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    run.B = B; run.tcs.assign(tcs, tcs + B); run.max_tc = max_tc; run.ids_total = ids_total;
+    return CZ_OK;
+}
+// append bytes to the payloads of this lane's group (between two advances)
+cz_status cz_dec_run_feed(cz_session* s, const uint8_t* const* chunks, const size_t* lens, int final_input) {
+    DecRun& run = s->run;
+    if (!run.active) { cz_set_error("no decode in progress on this session (cz_decode_begin_batch first)"); return CZ_ERR_STATE; }
+    if (!run.partial) { cz_set_error("cz_decode_feed_batch: this decode was begun with complete payloads"); return CZ_ERR_STATE; }
+    std::vector<unsigned long long> nl(run.B);
+    for (int b = 0; b < run.B; ++b) {
+        if (run.pay_len[b] + lens[b] > run.pay_cap[b]) { cz_set_error("cz_decode_feed_batch: stream %d would hold %zu bytes, capacity %zu", b, run.pay_len[b] + lens[b], run.pay_cap[b]); return CZ_ERR_ARG; }
+        if (lens[b]) HIPCHK(hipMemcpyAsync((uint8_t*)s->payload.p + run.pay_off[b] + run.pay_len[b], chunks[b], lens[b], hipMemcpyHostToDevice, s->stream));
+        run.pay_len[b] += lens[b]; nl[b] = run.pay_len[b];
+    }
+    HIPCHK(hipMemcpyAsync(s->sym.p, nl.data(), run.B * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(cz_launch_dec_feed(s->stream, (cz_dec_state*)s->decst.p, run.B, (const unsigned long long*)s->sym.p, final_input));
+    HIPCHK(hipStreamSynchronize(s->stream));                              // the host chunks may go away
+    return CZ_OK;
+}
+// ids decoded so far + the underrun check of a fed decode
+cz_status cz_dec_run_fetch(cz_session* s, uint32_t* const* out_ids) {
+    DecRun& run = s->run;
+    if (!run.active) { cz_set_error("no decode in progress on this session (cz_decode_begin_batch first)"); return CZ_ERR_STATE; }
+    std::vector<uint32_t> all(run.ids_total); std::vector<cz_dec_state> hs(run.B);
+    HIPCHK(hipMemcpyAsync(all.data(), s->outids.p, run.ids_total * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(hs.data(), s->decst.p, run.B * sizeof(cz_dec_state), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    size_t io = 0;
+    for (int b = 0; b < run.B; ++b) { memcpy(out_ids[b], all.data() + io, (run.tcs[b] + 1) * 4); if (run.tcs[b] == 0) out_ids[b][0] = run.bos; io += run.tcs[b] + 1; }
+    for (int b = 0; b < run.B; ++b)
+        if (hs[b].underrun) { cz_set_error("stream %d: the decoder read past the payload bytes fed so far (advance only as far as the bytes that have arrived allow)", b); return CZ_ERR_STATE; }
+    return CZ_OK;
+}
+static cz_status decode_llama_begin(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* caps, const size_t* tcs,
                                     uint32_t context_window, uint32_t R, uint32_t bos) {
     const cz_llama_config& c = s->llama.cfg;
     DecRun& run = s->run;
@@ -769,21 +827,8 @@ static cz_status decode_llama_begin(cz_session* s, int B, const uint8_t* const* 
     if (R == 0) { cz_set_error("reprime_interval must be > 0"); return CZ_ERR_ARG; }
     if (bos >= (uint32_t)c.vocab) { cz_set_error("bos id %u >= vocab", bos); return CZ_ERR_ARG; }
     CZCHK(ensure_streams(s, B));
-    size_t pay_total = 0, ids_total = 0, max_tc = 0;
-    for (int b = 0; b < B; ++b) { pay_total += lens[b] + 16; ids_total += tcs[b] + 1; max_tc = std::max(max_tc, tcs[b]); }
-    CZCHK(s->payload.ensure(pay_total)); CZCHK(s->outids.ensure(ids_total * 4)); CZCHK(s->decst.ensure(B * sizeof(cz_dec_state)));
-    std::vector<cz_dec_state> hs(B); std::vector<uint8_t> pay(pay_total, 0);
-    size_t po = 0, io = 0;
-    for (int b = 0; b < B; ++b) {
-        if (lens[b]) memcpy(pay.data() + po, payloads[b], lens[b]);
-        cz_dec_state d; memset(&d, 0, sizeof d);
-        d.in = (const uint8_t*)s->payload.p + po; d.in_len = lens[b]; d.out_ids = (uint32_t*)s->outids.p + io; d.token_count = tcs[b];
-        d.active = tcs[b] > 0;
-        hs[b] = d; po += lens[b] + 16; io += tcs[b] + 1;
-    }
-    HIPCHK(hipMemcpyAsync(s->payload.p, pay.data(), pay_total, hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipMemcpyAsync(s->decst.p, hs.data(), B * sizeof(cz_dec_state), hipMemcpyHostToDevice, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
+    CZCHK(cz_dec_run_setup(s, B, payloads, lens, caps, tcs));
+    const size_t max_tc = run.max_tc;
     cz_dec_state* dst = (cz_dec_state*)s->decst.p;
     HIPCHK(cz_launch_dec_init(s->stream, dst, B));                                           // ArithmeticDecoder::new (:2485)
     hipLaunchKernelGGL(init_out_ids_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, dst, B, bos);
@@ -819,8 +864,7 @@ static cz_status decode_llama_begin(cz_session* s, int B, const uint8_t* const* 
         CZCHK(llama_step(s, B, 0));                                                          // the dry run clobbered the BOS logits
     }
     hipLaunchKernelGGL(set_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, 1, 0ull);
-    run.B = B; run.tcs.assign(tcs, tcs + B); run.max_tc = max_tc; run.i = 0; run.index_pos = 1; run.ec = ec; run.R = R; run.bos = bos;
-    run.ids_total = ids_total; run.use_graph = use_graph; run.active = true;
+    run.i = 0; run.index_pos = 1; run.ec = ec; run.R = R; run.bos = bos; run.use_graph = use_graph; run.max_nk = max_nk; run.active = true;
     return CZ_OK;
 }
 // up to n more tokens of every stream of the group (streams shorter than the longest simply finish earlier)
@@ -831,6 +875,19 @@ static cz_status decode_llama_advance(cz_session* s, size_t n) {
     const int B = run.B; const size_t R = run.R, ec = run.ec;
     cz_dec_state* dst = (cz_dec_state*)s->decst.p;
     const size_t stop = run.max_tc - run.i < n ? run.max_tc : run.i + n;
+    if (run.use_graph && (s->graph_gen != s->devbuf_gen || s->graph_B != B || s->graph_max_nk != run.max_nk)) {
+        // another call on this session (an encode between two slices) grew a work buffer: the captured graph holds stale pointers.
+        // The step's own buffers are re-sized by the dry run inside build_step_graph; the logits of the pending step live in step_logits
+        // (never moved), so re-capturing here loses nothing.
+        std::vector<float> keep((size_t)B * s->llama.cfg.vocab);
+        HIPCHK(hipMemcpyAsync(keep.data(), s->step_logits, keep.size() * 4, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        CZCHK(build_step_graph(s, B, run.max_nk));
+        if (s->graph_gen != s->devbuf_gen) CZCHK(build_step_graph(s, B, run.max_nk));
+        HIPCHK(hipMemcpyAsync(s->step_logits, keep.data(), keep.size() * 4, hipMemcpyHostToDevice, s->stream));
+        hipLaunchKernelGGL(set_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, (int)run.index_pos, (unsigned long long)run.i);
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
     for (size_t i = run.i; i < stop; ++i) {
         size_t& index_pos = run.index_pos;
         if (index_pos >= ec && (i % R) == 0 && i > 0) {                                      // :2532
@@ -872,22 +929,11 @@ static cz_status decode_llama_advance(cz_session* s, size_t n) {
     HIPCHK(hipStreamSynchronize(s->stream));       // the slice is done when the call returns (and a faulting kernel is reported by this call)
     return CZ_OK;
 }
-// ids decoded so far (token_count + 1 per stream, BOS first; entries past the decoded position are unspecified)
-static cz_status decode_llama_fetch(cz_session* s, uint32_t* const* out_ids) {
-    DecRun& run = s->run;
-    if (!run.active) { cz_set_error("no decode in progress on this session (cz_decode_begin_batch first)"); return CZ_ERR_STATE; }
-    std::vector<uint32_t> all(run.ids_total);
-    HIPCHK(hipMemcpyAsync(all.data(), s->outids.p, run.ids_total * 4, hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
-    size_t io = 0;
-    for (int b = 0; b < run.B; ++b) { memcpy(out_ids[b], all.data() + io, (run.tcs[b] + 1) * 4); if (run.tcs[b] == 0) out_ids[b][0] = run.bos; io += run.tcs[b] + 1; }
-    return CZ_OK;
-}
 static cz_status decode_llama_group(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* tcs,
                                     uint32_t context_window, uint32_t R, uint32_t bos, uint32_t* const* out_ids) {
-    CZCHK(decode_llama_begin(s, B, payloads, lens, tcs, context_window, R, bos));
+    CZCHK(decode_llama_begin(s, B, payloads, lens, nullptr, tcs, context_window, R, bos));
     cz_status rc = decode_llama_advance(s, s->run.max_tc);
-    if (rc == CZ_OK) rc = decode_llama_fetch(s, out_ids);
+    if (rc == CZ_OK) rc = cz_dec_run_fetch(s, out_ids);
     s->run.active = false;
     return rc;
 }
@@ -1098,8 +1144,8 @@ static cz_status on_run_groups(cz_session* s, GroupFn group) {
     for (size_t g = 0; g < G; ++g) if (rc[g] != CZ_OK) { cz_set_error("%s", msg[g].c_str()); return rc[g]; }
     return CZ_OK;
 }
-extern "C" cz_status cz_decode_begin_batch(cz_session* s, size_t n_streams, const uint8_t* const* payloads, const size_t* lens, const size_t* token_counts,
-                                           uint32_t context_window, uint32_t reprime_interval, uint32_t bos) {
+static cz_status decode_begin_any(cz_session* s, size_t n_streams, const uint8_t* const* payloads, const size_t* lens, const size_t* caps, const size_t* token_counts,
+                                  uint32_t context_window, uint32_t reprime_interval, uint32_t bos) {
     if (cz_dead(s)) return CZ_ERR_STATE;
     if (!s || !payloads || !lens || !token_counts || n_streams == 0) { cz_set_error("cz_decode_begin_batch: null argument / no streams"); return CZ_ERR_ARG; }
     HIPCHK(hipSetDevice(s->device));
@@ -1115,11 +1161,27 @@ extern "C" cz_status cz_decode_begin_batch(cz_session* s, size_t n_streams, cons
     const bool rw = s->backend == CZ_BACKEND_RWKV7;
     const cz_status rc = on_run_groups(s, [&](cz_session* ls, size_t g) {
         const size_t o = s->run_off[g]; const int cnt = (int)(s->run_off[g + 1] - o);
-        return rw ? cz_rwkv7_decode_begin(ls, cnt, payloads + o, lens + o, token_counts + o, bos)
-                  : decode_llama_begin(ls, cnt, payloads + o, lens + o, token_counts + o, context_window, reprime_interval, bos);
+        return rw ? cz_rwkv7_decode_begin(ls, cnt, payloads + o, lens + o, caps ? caps + o : nullptr, token_counts + o, bos)
+                  : decode_llama_begin(ls, cnt, payloads + o, lens + o, caps ? caps + o : nullptr, token_counts + o, context_window, reprime_interval, bos);
     });
     if (rc != CZ_OK) s->run_off.clear();
     return rc;
+}
+extern "C" cz_status cz_decode_begin_batch(cz_session* s, size_t n_streams, const uint8_t* const* payloads, const size_t* lens, const size_t* token_counts,
+                                           uint32_t context_window, uint32_t reprime_interval, uint32_t bos) {
+    return decode_begin_any(s, n_streams, payloads, lens, nullptr, token_counts, context_window, reprime_interval, bos);
+}
+extern "C" cz_status cz_decode_begin_partial_batch(cz_session* s, size_t n_streams, const uint8_t* const* payloads, const size_t* lens, const size_t* payload_caps,
+                                                   const size_t* token_counts, uint32_t context_window, uint32_t reprime_interval, uint32_t bos) {
+    if (!payload_caps) { cz_set_error("cz_decode_begin_partial_batch: null capacities"); return CZ_ERR_ARG; }
+    return decode_begin_any(s, n_streams, payloads, lens, payload_caps, token_counts, context_window, reprime_interval, bos);
+}
+extern "C" cz_status cz_decode_feed_batch(cz_session* s, size_t n_streams, const uint8_t* const* chunks, const size_t* lens, int final_input) {
+    if (cz_dead(s)) return CZ_ERR_STATE;
+    if (!s || !chunks || !lens) { cz_set_error("cz_decode_feed_batch: null argument"); return CZ_ERR_ARG; }
+    if (s->run_off.empty() || n_streams != s->run_off.back()) { cz_set_error("cz_decode_feed_batch: %zu streams, the decode in progress has %zu", n_streams, s->run_off.empty() ? (size_t)0 : s->run_off.back()); return CZ_ERR_ARG; }
+    HIPCHK(hipSetDevice(s->device));
+    return on_run_groups(s, [&](cz_session* ls, size_t g) { return cz_dec_run_feed(ls, chunks + s->run_off[g], lens + s->run_off[g], final_input); });
 }
 extern "C" cz_status cz_decode_advance(cz_session* s, size_t n_tokens, size_t* position, size_t* remaining) {
     if (cz_dead(s)) return CZ_ERR_STATE;
@@ -1141,8 +1203,7 @@ extern "C" cz_status cz_decode_fetch_batch(cz_session* s, size_t n_streams, uint
     if (!s || !out_ids) { cz_set_error("cz_decode_fetch_batch: null argument"); return CZ_ERR_ARG; }
     if (s->run_off.empty() || n_streams != s->run_off.back()) { cz_set_error("cz_decode_fetch_batch: %zu streams, the decode in progress has %zu", n_streams, s->run_off.empty() ? (size_t)0 : s->run_off.back()); return CZ_ERR_ARG; }
     HIPCHK(hipSetDevice(s->device));
-    const bool rw = s->backend == CZ_BACKEND_RWKV7;
-    return on_run_groups(s, [&](cz_session* ls, size_t g) { return rw ? cz_rwkv7_decode_fetch(ls, out_ids + s->run_off[g]) : decode_llama_fetch(ls, out_ids + s->run_off[g]); });
+    return on_run_groups(s, [&](cz_session* ls, size_t g) { return cz_dec_run_fetch(ls, out_ids + s->run_off[g]); });
 }
 extern "C" cz_status cz_decode_end(cz_session* s) {
     if (!s) return CZ_ERR_ARG;
@@ -1239,7 +1300,7 @@ extern "C" cz_status cz_debug_decode_steps(cz_session* s, int B, int pos, int it
         std::vector<cz_dec_state> hs(B);
         for (int b = 0; b < B; ++b) {
             cz_dec_state d; memset(&d, 0, sizeof d);
-            d.in = (const uint8_t*)s->payload.p + (size_t)b * 64; d.in_len = 64; d.out_ids = (uint32_t*)s->outids.p + (size_t)b * 4; d.token_count = 1u << 30; d.active = 1;
+            d.in = (const uint8_t*)s->payload.p + (size_t)b * 64; d.in_len = 64; d.out_ids = (uint32_t*)s->outids.p + (size_t)b * 4; d.token_count = 1u << 30; d.active = 1; d.final_input = 1;
             hs[b] = d;
         }
         HIPCHK(hipMemcpyAsync(s->decst.p, hs.data(), B * sizeof(cz_dec_state), hipMemcpyHostToDevice, s->stream));

@@ -118,6 +118,13 @@ cz_status cz_encode_tokens_range_batch(cz_session* s, size_t n_streams, const ui
  * begin + advance(everything) + fetch + end.  One decode in progress per session. */
 cz_status cz_decode_begin_batch(cz_session* s, size_t n_streams, const uint8_t* const* payloads, const size_t* lens,
                                 const size_t* token_counts, uint32_t context_window, uint32_t reprime_interval, uint32_t bos);
+/* Payloads that arrive in pieces (a file still being read, or an encoder still running): begin with the bytes at hand and a capacity per
+ * stream, append with feed (final != 0 with the last bytes: only then do reads past the end mean the reference's EOF bits, src/main.rs:432),
+ * and advance no further than the bytes fed allow — the decoder looks 32 bits ahead of the symbol it decodes.  A decoder that did read past
+ * unfed bytes is reported by cz_decode_fetch_batch (CZ_ERR_STATE), never silently. */
+cz_status cz_decode_begin_partial_batch(cz_session* s, size_t n_streams, const uint8_t* const* payloads, const size_t* lens, const size_t* payload_caps,
+                                        const size_t* token_counts, uint32_t context_window, uint32_t reprime_interval, uint32_t bos);
+cz_status cz_decode_feed_batch(cz_session* s, size_t n_streams, const uint8_t* const* chunks, const size_t* lens, int final_input);
 cz_status cz_decode_advance(cz_session* s, size_t n_tokens, size_t* position, size_t* remaining);
 cz_status cz_decode_fetch_batch(cz_session* s, size_t n_streams, uint32_t* const* out_ids);
 cz_status cz_decode_end(cz_session* s);
@@ -139,6 +146,14 @@ cz_status cz_xe_bits_batch(cz_session* s, size_t n_spans, const uint32_t* const*
 cz_status cz_ac_encode_pairs(const uint32_t* c_lo, const uint32_t* c_hi, size_t n, uint8_t** payload, size_t* len,
                              uint64_t* zero_width);
 void cz_free(void* p);
+/* The same encoder fed in pieces (ArithmeticEncoder::encode_counts called window by window, src/main.rs:2300): push returns the bytes that
+ * became final with these intervals (*new_bytes points into the encoder, valid until the next call), finish the last ones
+ * (src/main.rs:387-399).  The concatenation equals cz_ac_encode_pairs over all the intervals. */
+typedef struct cz_ac_encoder cz_ac_encoder;
+cz_status cz_ac_encoder_new(cz_ac_encoder** out);
+cz_status cz_ac_encoder_push(cz_ac_encoder* e, const uint32_t* c_lo, const uint32_t* c_hi, size_t n, const uint8_t** new_bytes, size_t* new_len);
+cz_status cz_ac_encoder_finish(cz_ac_encoder* e, const uint8_t** new_bytes, size_t* new_len, size_t* total_len, uint64_t* zero_width);
+void cz_ac_encoder_free(cz_ac_encoder* e);
 
 /* .canz container, header v2 (src/main.rs:551-646) */
 typedef struct cz_header {

@@ -85,3 +85,23 @@ def test_product_does_not_touch_the_oracle():
                 if f.endswith((".py", ".h", ".hip", ".cpp", "Makefile")):
                     txt = open(os.path.join(dp, f), errors="replace").read()
                     assert "czo_" not in txt and "cz_oracle" not in txt and "oracle/" not in txt.replace("CPU oracle", ""), os.path.join(dp, f)
+
+
+def test_incremental_encoder_equals_one_shot(cz):
+    """cz_ac_encoder_* (ArithmeticEncoder::encode_counts called window by window): the pieces concatenate to cz_ac_encode_pairs' payload"""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 7, 3000):
+        lo = np.sort(rng.integers(0, 1 << 30, (n, 2)), axis=1).astype(np.uint32)
+        lo[:, 1] = np.maximum(lo[:, 1], lo[:, 0] + (rng.integers(0, 4, n) > 0))        # a few zero-width intervals too
+        ref, zw = cz.ac_encode_pairs(lo[:, 0], lo[:, 1])
+        e = cz.AcEncoder()
+        got = b""; k = 0
+        for w in (1, 5, 0, 250, 10 ** 6):
+            got += e.push(lo[k:k + w, 0], lo[k:k + w, 1]); k += w
+            assert ref.startswith(got)                                                  # every piece is final when it comes out
+        tail, zw2 = e.finish()
+        assert got + tail == ref and zw2 == zw
+        with pytest.raises(cz.CandlezipError):
+            e.push(lo[:1, 0], lo[:1, 1])
+        e.close()

@@ -216,3 +216,58 @@ def test_wide_group_step_is_bitexact(cz, czo, shape, path):
                 assert np.array_equal(out, s_)
     g.debug_set("dec_wide_rows", 256); g.debug_set("dec_attn_small_grid", 128)
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("backend", ["smollm", "rwkv7"])
+def test_decode_with_payloads_fed_in_pieces(cz, backend):
+    """cz_decode_begin_partial_batch / cz_decode_feed_batch: the encoder runs ahead of the decoder window by window (cz_ac_encoder_*), the
+    decoder only ever sees the bytes that are final; ids equal the one-shot decode.  Advancing past what the fed bytes allow is reported."""
+    if backend == "smollm":
+        g = cz.Session("smollm", cz.tiny_llama_config(), seed=11, embed_std=0.05, max_streams=2)
+        V = 512
+    else:
+        g = cz.Session("rwkv7", cz.tiny_rwkv7_config(), seed=9, embed_std=0.05, max_streams=2)
+        V = 512 + 256
+    g.debug_set("max_lanes", 2)
+    rng = np.random.default_rng(31)
+    lens = [1300, 900, 1300]                                                       # two groups on two lanes
+    streams = [np.concatenate([[0], rng.integers(0, V, n)]).astype(np.uint32) for n in lens]
+    pairs = g.encode_tokens_batch(streams)
+    W, LAG = 256, 2
+    encs = [cz.AcEncoder() for _ in streams]
+    pieces = [[] for _ in streams]
+    nwin = -(-max(lens) // W)
+
+    def compress_window(w):
+        for k, (lo, hi) in enumerate(pairs):
+            b, e = w * W, min((w + 1) * W, lens[k])
+            if b < lens[k]:
+                pieces[k].append(encs[k].push(lo[b:e], hi[b:e]))
+                if e == lens[k]:
+                    pieces[k][-1] += encs[k].finish()[0]
+            else:
+                pieces[k].append(b"")
+    for w in range(LAG):
+        compress_window(w)
+    first = [b"".join(p) for p in pieces]
+    g.decode_begin_partial_batch(first, [4 * n + 16 for n in lens], lens)
+    for w in range(nwin):
+        if w + LAG < nwin:
+            compress_window(w + LAG)
+            g.decode_feed_batch([p[w + LAG] for p in pieces], final=(w + LAG == nwin - 1))
+        g.decode_advance(W)
+    outs = g.decode_fetch_batch()
+    g.decode_end()
+    for s_, o in zip(streams, outs):
+        assert np.array_equal(s_, o)
+    assert [b"".join(p) for p in pieces] == [cz.ac_encode_pairs(lo, hi)[0] for lo, hi in pairs]
+    # starved decoder: only the first window's bytes, yet all tokens requested -> reported, not silent
+    g.decode_begin_partial_batch([p[0] for p in pieces], [4 * n + 16 for n in lens], lens)
+    g.decode_advance(max(lens))
+    with pytest.raises(cz.CandlezipError, match="fed so far"):
+        g.decode_fetch_batch()
+    g.decode_end()
+    with pytest.raises(cz.CandlezipError):
+        g.decode_begin_batch(first, lens); g.decode_feed_batch([b"x"] * 3)        # a decode begun with complete payloads takes no feed
+    g.decode_end()
+    g.close()
