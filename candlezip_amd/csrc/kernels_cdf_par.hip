@@ -57,11 +57,22 @@ template <int LMAX> struct par_smem_t {
     int ok;
 };
 
-template <class SM> __device__ __forceinline__ double block_excl_scan(double v, SM& sm) {     // approximate (any order): only guesses binades
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Lane shuffles with the lane index passed in.  The kernels launder their thread index through an empty asm once per row, so the
+// permute addresses (and everything else derived from the thread index) are NOT loop invariants: hoisted out of the row loop they
+// stay live across the whole body — ~45 VGPRs and ~100 SGPRs that the 128-register budget of a 1024-thread block then spills.
+__device__ __forceinline__ int shfl_up_i(int v, int o, int lane) { return __builtin_amdgcn_ds_bpermute(((lane - o) & 63) << 2, v); }   // callers guard lane >= o
+__device__ __forceinline__ double shfl_up_d(double v, int o, int lane) {
+    const int a = ((lane - o) & 63) << 2;
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(a, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(a, __double2loint(v)));
+}
+__device__ __forceinline__ float shfl_xor_f(float v, int o, int lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ o) << 2, __float_as_int(v))); }
+__device__ __forceinline__ int launder(int v) { asm volatile("" : "+v"(v)); return v; }
+
+template <class SM> __device__ __forceinline__ double block_excl_scan(double v, SM& sm, int tid) {     // approximate (any order): only guesses binades
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double inc = v;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { double y = __shfl_up(inc, o); if (lane >= o) inc += y; }
+    for (int o = 1; o < 64; o <<= 1) { double y = shfl_up_d(inc, o, lane); if (lane >= o) inc += y; }
     if (lane == 63) sm.wsum[wave] = inc;
     __syncthreads();
     double base = 0.0;
@@ -98,11 +109,11 @@ __device__ unsigned long long g_cdf_phase[16];
 // csum = APPROXIMATE sum of this thread's terms (any rounding; it only feeds the binade guesses).
 template <int LMAX, typename XF>
 __device__ __forceinline__ double exact_seq_sum(XF xf, double csum, int cnt, int first, par_smem_t<LMAX>& sm, double* scratch, bool want_acc_in,
-                                                double* acc_in_out, unsigned long long& ph_t) {
+                                                double* acc_in_out, unsigned long long& ph_t, int tid) {
     static_assert(LMAX <= 128, "the resolve holds a chunk's terms in two registers per lane");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) sm.pool_next = 0;
-    const double pstart = block_excl_scan(csum, sm);            // (contains barriers: the reset above is visible afterwards)
+    const double pstart = block_excl_scan(csum, sm, tid);            // (contains barriers: the reset above is visible afterwards)
     const double pend = pstart + csum;
     PH(8);
     int b = B_INVALID; double d0 = 0.0, d1 = 0.0;
@@ -153,8 +164,8 @@ __device__ __forceinline__ double exact_seq_sum(XF xf, double csum, int cnt, int
     int hidx = head ? tid : -1;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        tdx u; u.d0 = __shfl_up(v.d0, o); u.d1 = __shfl_up(v.d1, o); u.p = __shfl_up(v.p, o);
-        const int uf = __shfl_up(flag, o), uh = __shfl_up(hidx, o);
+        tdx u; u.d0 = shfl_up_d(v.d0, o, lane); u.d1 = shfl_up_d(v.d1, o, lane); u.p = shfl_up_i(v.p, o, lane);
+        const int uf = shfl_up_i(flag, o, lane), uh = shfl_up_i(hidx, o, lane);
         if (lane >= o) {
             if (!flag) v = td_compose(u, v);
             flag |= uf;
@@ -164,7 +175,7 @@ __device__ __forceinline__ double exact_seq_sum(XF xf, double csum, int cnt, int
     // head count prefix (for compaction)
     int hc = head ? 1 : 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(hc, o); if (lane >= o) hc += y; }
+    for (int o = 1; o < 64; o <<= 1) { const int y = shfl_up_i(hc, o, lane); if (lane >= o) hc += y; }
     if (lane == 63) { sm.wD0[wave] = v.d0; sm.wD1[wave] = v.d1; sm.wp[wave] = v.p; sm.wflag[wave] = flag; sm.wcnt[wave] = hc; sm.whead[wave] = hidx; }
     __syncthreads();
     {
@@ -261,21 +272,20 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
     __shared__ par_smem_t<LMAX> sm;
     if (DECODE && step_dev) step_i = *step_dev;
     if (!DECODE && step_dev) { c_lo += *step_dev * (unsigned long long)rows; c_hi += *step_dev * (unsigned long long)rows; }   // lock-step encode under graph replay
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = MODE ? V + 256 : V;                              // symbols of the coded alphabet
     double* scratch = scratch_all + (size_t)blockIdx.x * n;
     int L = (n + T_PAR - 1) / T_PAR;
     if (L >= 8) L = (L + 3) & ~3;                                  // chunks start on 16-B boundaries: 4 logits per load
     if (FULL) L = LMAX;
-    const int first = tid * L;
-    const int cntA = FULL ? LMAX : (first >= V ? 0 : (V - first < L ? V - first : L));       // owned vocabulary entries (terms of the chains over V)
-    const int cnt = FULL ? LMAX : (first >= n ? 0 : (n - first < L ? n - first : L));        // owned symbols (vocabulary, then literals)
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
-        cz_dec_state d;
-        if (DECODE) {
-            d = dst[row];
-            if (!d.active || step_i >= d.token_count) {       // uniform across the block
-                if (tid == 0 && d.active) { d.active = 0; dst[row] = d; }
+        const int tid = launder((int)threadIdx.x), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // see shfl_up_i
+        const int first = tid * L;
+        const int cntA = FULL ? LMAX : (first >= V ? 0 : (V - first < L ? V - first : L));       // owned vocabulary entries (terms of the chains over V)
+        const int cnt = FULL ? LMAX : (first >= n ? 0 : (n - first < L ? n - first : L));        // owned symbols (vocabulary, then literals)
+        if (DECODE) {                                         // only thread 0 ever holds the whole decoder state (it lives in memory, not in 1024 x 24 registers)
+            const unsigned active = dst[row].active;
+            if (!active || step_i >= dst[row].token_count) {  // uniform across the block
+                if (tid == 0 && active) dst[row].active = 0;
                 continue;
             }
         }
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
 #pragma unroll
         for (int k = 0; k < LMAX; ++k) if (k < cntA && ef[k] > m) m = ef[k];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { float y = __shfl_xor(m, o); m = y > m ? y : m; }
+        for (int o = 32; o > 0; o >>= 1) { float y = shfl_xor_f(m, o, lane); m = y > m ? y : m; }
         if (lane == 0) sm.redf[wave] = m;
         __syncthreads();
         m = sm.redf[0];
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
 #pragma unroll
         for (int k = 0; k < LMAX; ++k) if (k < cntA) csum_e += (double)ef[k];
         PH(0);
-        const double sum = exact_seq_sum<LMAX>([&](int k) { return (double)ef[k]; }, csum_e, cntA, first, sm, scratch, false, nullptr, ph_t);
+        const double sum = exact_seq_sum<LMAX>([&](int k) { return (double)ef[k]; }, csum_e, cntA, first, sm, scratch, false, nullptr, ph_t, tid);
         PH(1);
         bool fallback = sm.flag != 0 || !(sum > 0.0);            // sum <= 0 (uniform pdf, :794) or NaN: take the serial walk
         double acc = 0.0;
@@ -341,33 +351,32 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
             double cs = 0.0;
 #pragma unroll
             for (int k = 0; k < LMAX; ++k) if (k < cntA) { const double p = (double)ef[k] * inv_sum; cs += p > P_MIN ? p : P_MIN; }
-            norm = exact_seq_sum<LMAX>(fl, cs, cntA, first, sm, scratch, false, nullptr, ph_t);
+            norm = exact_seq_sum<LMAX>(fl, cs, cntA, first, sm, scratch, false, nullptr, ph_t, tid);
             PH(2);
             fallback = sm.flag != 0 || !(norm > 0.0);
             if (!fallback) {
                 if (tid == 0) sm.n = n;                          // the last two chains run over vocabulary + literals
                 const double cs2 = cs * (scale / norm) + (double)(cnt - cntA) * lit;
-                sum2 = exact_seq_sum<LMAX>(mix, cs2, cnt, first, sm, scratch, false, nullptr, ph_t);
+                sum2 = exact_seq_sum<LMAX>(mix, cs2, cnt, first, sm, scratch, false, nullptr, ph_t, tid);
                 PH(3);
                 fallback = sm.flag != 0 || !(sum2 > 0.0);
                 if (!fallback) {
-                    exact_seq_sum<LMAX>(pd, cs2 / sum2, cnt, first, sm, scratch, true, &acc, ph_t);
+                    exact_seq_sum<LMAX>(pd, cs2 / sum2, cnt, first, sm, scratch, true, &acc, ph_t, tid);
                     fallback = sm.flag != 0;
                 }
             }
         }
         if (MODE == 0 && !fallback) {
-            exact_seq_sum<LMAX>(pd, csum_e / sum, cnt, first, sm, scratch, true, &acc, ph_t);
+            exact_seq_sum<LMAX>(pd, csum_e / sum, cnt, first, sm, scratch, true, &acc, ph_t, tid);
             fallback = sm.flag != 0;
         }
         if (fallback) {                                          // rare: exact serial walk by one lane
             if (tid == 0) {
                 if (fallback_count) atomicAdd(fallback_count, 1u);
                 if (DECODE) {
-                    uint32_t s = 0;
-                    if (serial_decode_row(l, V, MODE, d, &s)) { d.out_ids[step_i + 1] = s; sym_out[row] = s; }
-                    else { d.active = 0; sym_out[row] = 0; }
-                    dst[row] = d;
+                    uint32_t s = 0;                          // (the state stays in memory: a local copy handed to a call would cost every lane a stack frame)
+                    if (serial_decode_row(l, V, MODE, dst[row], &s)) { dst[row].out_ids[step_i + 1] = s; sym_out[row] = s; }
+                    else { dst[row].active = 0; sym_out[row] = 0; }
                 } else {
                     uint32_t lo, hi;
                     serial_pairs_row(l, V, MODE, sym[row], &lo, &hi);
@@ -384,24 +393,25 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
             const uint32_t s = sym[row];
             if (tid == 0 && s >= (uint32_t)n) { c_lo[row] = 0; c_hi[row] = 0; }
             if (cnt > 0 && s >= (uint32_t)first && s < (uint32_t)(first + cnt)) {
+                const int srel = (int)s - first;                                        // the symbol's place inside this chunk
                 uint32_t lo = s == 0 ? 0u : quantize_u(acc_in), hi = 0;                 // cdf[first] (value when s == first)
 #pragma unroll
                 for (int k = 0; k < LMAX; ++k)
-                    if (k < cnt && (uint32_t)(first + k) <= s) {
+                    if (k < cnt && k <= srel) {
                         acc = acc + pd(k);
-                        const uint32_t i = (uint32_t)(first + k);
-                        const uint32_t v = (i + 1 == (uint32_t)n) ? CDF_TOTAL_U : quantize_u(acc);   // cdf[n] = total forced (:822, :2321)
-                        if (i + 1 == s) lo = v;
-                        if (i == s) hi = v;
+                        const uint32_t v = quantize_u(acc);
+                        if (k + 1 == srel) lo = v;
+                        if (k == srel) hi = v;
                     }
+                if (s + 1 == (uint32_t)n) hi = CDF_TOTAL_U;                              // cdf[n] = total forced (:822, :2321)
                 c_lo[row] = lo; c_hi[row] = hi;
             }
         } else {
-            if (tid == 0) { bool ok; sm.value = dec_value(d, ok); sm.ok = ok ? 1 : 0; }
+            if (tid == 0) { bool ok; sm.value = dec_value(dst[row], ok); sm.ok = ok ? 1 : 0; }
             sm.bexp[tid] = cnt > 0 ? (int)quantize_u(acc_in) : (int)CDF_TOTAL_U;        // cdf[first] of every chunk (bexp is free between chains)
             __syncthreads();
             if (!sm.ok) {                                        // the reference would panic (range == 0)
-                if (tid == 0) { d.active = 0; dst[row] = d; sym_out[row] = 0; }
+                if (tid == 0) { dst[row].active = 0; sym_out[row] = 0; }
                 __syncthreads();
                 continue;
             }
@@ -418,16 +428,17 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
                 for (int k = 0; k < LMAX; ++k)
                     if (k < cnt) {
                         acc = acc + pd(k);
-                        const uint32_t i = (uint32_t)(first + k);
-                        const uint32_t v = (i + 1 == (uint32_t)n) ? CDF_TOTAL_U : quantize_u(acc);
-                        if ((v > value || i + 1 == (uint32_t)n) && mine == 0xffffffffu) { mine = i; my_lo = prev; my_hi = v; }   // cdf[i] <= value < cdf[i+1]
+                        const bool forced = last_chunk && k + 1 == cnt;                 // cdf[n] = total forced (:822, :2321)
+                        const uint32_t v = forced ? CDF_TOTAL_U : quantize_u(acc);
+                        if ((v > value || forced) && mine == 0xffffffffu) { mine = (unsigned)k; my_lo = prev; my_hi = v; }   // cdf[i] <= value < cdf[i+1]
                         prev = v;
                     }
-                sm.found = mine; sm.lo = my_lo; sm.hi = my_hi;
+                sm.found = (unsigned)first + mine; sm.lo = my_lo; sm.hi = my_hi;
             }
             __syncthreads();
             const uint32_t s = sm.found;
             if (tid == 0) {
+                cz_dec_state d = dst[row];
                 dec_update(d, sm.lo, sm.hi);
                 d.out_ids[step_i + 1] = s;
                 sym_out[row] = s;
@@ -453,14 +464,14 @@ template <int LMAX>
 __global__ __launch_bounds__(T_PAR) void xe_prob_kernel(const float* __restrict__ logits, int ld, int rows, int V, const uint32_t* __restrict__ sym,
                                                         double* __restrict__ p_out, double* __restrict__ scratch_all, unsigned* __restrict__ fallback_count) {
     __shared__ par_smem_t<LMAX> sm;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* scratch = scratch_all + (size_t)blockIdx.x * V;
     int L = (V + T_PAR - 1) / T_PAR;
     if (L >= 8) L = (L + 3) & ~3;
-    const int first = tid * L;
-    const int cnt = first >= V ? 0 : (V - first < L ? V - first : L);
     unsigned long long ph_t = 0;
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int tid = launder((int)threadIdx.x), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int first = tid * L;
+        const int cnt = first >= V ? 0 : (V - first < L ? V - first : L);
         const float* l = logits + (size_t)row * ld;
         if (tid == 0) { sm.flag = 0; sm.L = L; sm.n = V; }
         float ef[LMAX];
@@ -468,7 +479,7 @@ __global__ __launch_bounds__(T_PAR) void xe_prob_kernel(const float* __restrict_
 #pragma unroll
         for (int k = 0; k < LMAX; ++k) if (k < cnt) { ef[k] = l[first + k]; if (ef[k] > m) m = ef[k]; }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { float y = __shfl_xor(m, o); m = y > m ? y : m; }
+        for (int o = 32; o > 0; o >>= 1) { float y = shfl_xor_f(m, o, lane); m = y > m ? y : m; }
         if (lane == 0) sm.redf[wave] = m;
         __syncthreads();
         m = sm.redf[0];
@@ -478,7 +489,7 @@ __global__ __launch_bounds__(T_PAR) void xe_prob_kernel(const float* __restrict_
         double csum_e = 0.0;
 #pragma unroll
         for (int k = 0; k < LMAX; ++k) if (k < cnt) { ef[k] = cz_expf(ef[k] - m); csum_e += (double)ef[k]; }
-        const double sum = exact_seq_sum<LMAX>([&](int k) { return (double)ef[k]; }, csum_e, cnt, first, sm, scratch, false, nullptr, ph_t);
+        const double sum = exact_seq_sum<LMAX>([&](int k) { return (double)ef[k]; }, csum_e, cnt, first, sm, scratch, false, nullptr, ph_t, tid);
         bool fallback = sm.flag != 0 || !(sum > 0.0);
         auto fl = [&](int k) { const double p = (double)ef[k] / sum; return p > P_MIN ? p : P_MIN; };
         double norm = 1.0;
@@ -487,7 +498,7 @@ __global__ __launch_bounds__(T_PAR) void xe_prob_kernel(const float* __restrict_
             double cs = 0.0;
 #pragma unroll
             for (int k = 0; k < LMAX; ++k) if (k < cnt) { const double p = (double)ef[k] * inv_sum; cs += p > P_MIN ? p : P_MIN; }
-            norm = exact_seq_sum<LMAX>(fl, cs, cnt, first, sm, scratch, false, nullptr, ph_t);
+            norm = exact_seq_sum<LMAX>(fl, cs, cnt, first, sm, scratch, false, nullptr, ph_t, tid);
             fallback = sm.flag != 0 || !(norm > 0.0);
         }
         const uint32_t s = sym[row];

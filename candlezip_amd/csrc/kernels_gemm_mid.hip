@@ -9,8 +9,9 @@
 //   * block = ONE 32 x (32 TN) output tile, four waves = four K GROUPS: wave g owns K tiles g, g+4, ...  The M/32 x N/(32 TN) grid is
 //     432 blocks for the 768 x 576 o-projection, 2304 for gate|up.
 //   * the ordered sum of the chunk partials crosses the waves through LDS: every round (4 K tiles) waves 1..3 park their partial tiles
-//     in a double-buffered slot, ONE barrier, and wave 0 adds them — in K order — to the running total while the next round's MFMAs are
-//     already issued.  No wave ever waits for another one's MFMAs inside a round.
+//     in a slot, ONE barrier, and wave 0 adds them — in K order — to the running total at the START of the next round, then raises an
+//     LDS flag; the other waves check that flag (long since raised: their MFMA chain lies in between) before they overwrite the slot.
+//     One slot set instead of two keeps a gate|up block at 59 KB of LDS, so that two blocks share a CU (three for TN = 1).
 //   * weights are read straight into MFMA operand registers from a copy packed for v_mfma_f32_32x32x2_f32 ("k2": per row and 64-k chunk
 //     the even k, then the odd k, so that lane (n, h) loads its 32 operands k = 2t + h as 64 contiguous bytes); only the activations
 //     pass through LDS (a wave-private 32 x 64 tile: no block barrier for staging).
@@ -22,18 +23,28 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MID_LDK 68   // LDS row stride of the activation tile in floats (64 + 4: ds_read_b128 by 16 consecutive rows is conflict-free)
 
-// Wk[n][c*64 + h*32 + t] = W[n][c*64 + 2t + h]
-__global__ void k2_pack_kernel(const uint16_t* __restrict__ W, uint16_t* __restrict__ Wk, size_t N, int K) {
+// Wk[n'][c*64 + h*32 + t] = W[n][c*64 + 2t + h].  The first `rot_heads` 64-row heads are stored with their rows reordered so that a
+// 32-column output block holds 16 RoPE pairs (j, j + 32) of ONE head: n' = 64 head + 32 b + r takes row 16 b + (r & 15) + 32 (r >> 4).
+__global__ void k2_pack_kernel(const uint16_t* __restrict__ W, uint16_t* __restrict__ Wk, size_t N, int K, int rot_heads) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < N * (size_t)K; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t n = i / K; const int k = (int)(i % K);
-        Wk[n * K + (k & ~63) + (k & 1) * 32 + ((k & 63) >> 1)] = W[i];
+        const size_t np = i / K; const int k = (int)(i % K);
+        size_t n = np;
+        if (np < (size_t)rot_heads * 64) { const int j = (int)(np & 63), b = j >> 5, r = j & 31; n = (np & ~(size_t)63) + 16 * b + (r & 15) + 32 * (r >> 4); }
+        Wk[np * K + (k & ~63) + (k & 1) * 32 + ((k & 63) >> 1)] = W[n * K + k];
     }
 }
-hipError_t cz_launch_k2_pack(hipStream_t st, const uint16_t* W, uint16_t* Wk, size_t N, int K) {
-    if (K % 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k2_pack_kernel, dim3(2048), dim3(256), 0, st, W, Wk, N, K);
+hipError_t cz_launch_k2_pack(hipStream_t st, const uint16_t* W, uint16_t* Wk, size_t N, int K, int rot_heads) {
+    if (K % 64 || (size_t)rot_heads * 64 > N) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k2_pack_kernel, dim3(2048), dim3(256), 0, st, W, Wk, N, K, rot_heads);
     return hipGetLastError();
 }
+struct mid_rope_args {          // EPI = 2: the fused-QKV projection of one lock-step decode step
+    const cz_rope_desc* descs;  // per stream (= output row): where its K / V cache lives
+    const float* cs; const float* sn;
+    const int* pos_dev;
+    size_t kv_off;
+    int n_heads, n_kv;
+};
 
 __device__ __forceinline__ int mid_xcd_remap(int bid, int nblocks) {    // blocks b and b + 8 share an XCD (speed only): contiguous tile ranges per XCD
     int q = nblocks >> 3, r = nblocks & 7, x = bid & 7;
@@ -42,14 +53,18 @@ __device__ __forceinline__ int mid_xcd_remap(int bid, int nblocks) {    // block
 }
 
 // EPI = 0: C = A.W^T (+ R).  EPI = 1 (TN = 2): W rows interleaved gate|up by 32 (cz_launch_gu_interleave): H[M][N/2] = silu(gate) * up.
+// EPI = 2 (TN = 1): the fused QKV projection with the head rows reordered by cz_launch_k2_pack(rot_heads = n_heads + n_kv): RoPE
+// (candle_nn::rotary_emb::rope, non-interleaved halves, products rounded separately) in the epilogue; q goes to C, k (rotated) and v
+// straight to the stream's KV cache at *pos_dev — what rope_kernel did in a launch of its own.
 template <int TN, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_mid_kernel(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Wk,
                                                           float* __restrict__ C, int ldc, const float* __restrict__ R, int ldr,
-                                                          int M, int N, int K, int nbx, int nblocks) {
+                                                          int M, int N, int K, int nbx, int nblocks, mid_rope_args ra_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* As = smem + wave * (32 * MID_LDK);                            // wave-private activation tile [32][MID_LDK]
-    float* slots = smem + 4 * (32 * MID_LDK);                            // [2][3][TN][16][64] partial tiles of waves 1..3
+    float* slots = smem + 4 * (32 * MID_LDK);                            // [3][TN][16][64] partial tiles of waves 1..3
+    int* consumed = reinterpret_cast<int*>(slots + 3 * TN * 1024);       // round up to which wave 0 has taken the slots over
     const int sid = mid_xcd_remap(blockIdx.x, nblocks);
     const int bm = sid / nbx, bn = sid % nbx;
     const int lr = lane & 31, lh = lane >> 5;
@@ -92,6 +107,21 @@ __global__ __launch_bounds__(256, 2) void gemm_mid_kernel(const float* __restric
     if (wave < nk) load_tile(wave);
     for (int rd = 0; rd < rounds; ++rd) {
         const int kt = rd * 4 + wave;
+        if (wave == 0) {
+            // chunk partials of the previous round's waves 1..3, in K order (complete since the barrier that ended that round)
+            if (rd > 0) {
+#pragma unroll
+                for (int w = 0; w < 3; ++w)
+                    if ((rd - 1) * 4 + 1 + w < nk) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) tot[j][r] = tot[j][r] + slots[((w * TN + j) * 16 + r) * 64 + lane];
+                    }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(consumed, rd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         f32x16 acc[TN];
         if (kt < nk) {
             unsigned wb[TN][16];
@@ -123,49 +153,70 @@ __global__ __launch_bounds__(256, 2) void gemm_mid_kernel(const float* __restric
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_s_waitcnt(0xc07f);                        // (the reads of As are done before the next round overwrites it)
-        }
-        if (wave == 0) {
-            // chunk partials of the previous round's waves 1..3, in K order, then this round's own chunk
-            if (rd > 0) {
-                const float* sp = slots + ((rd - 1) & 1) * (3 * TN * 1024);
-#pragma unroll
-                for (int w = 0; w < 3; ++w)
-                    if ((rd - 1) * 4 + 1 + w < nk) {
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) tot[j][r] = tot[j][r] + sp[((w * TN + j) * 16 + r) * 64 + lane];
-                    }
-            }
-            if (kt < nk) {
+            if (wave == 0) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) tot[j][r] = rd == 0 ? acc[j][r] : tot[j][r] + acc[j][r];
+            } else {
+                if (rd > 0) {                                           // wave 0 has taken over the previous round's partials (it did so a whole MFMA chain ago)
+                    while (__hip_atomic_load(consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rd) __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+                float* sp = slots + (wave - 1) * TN * 1024;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sp[(j * 16 + r) * 64 + lane] = acc[j][r];
             }
-        } else if (kt < nk) {
-            float* sp = slots + (rd & 1) * (3 * TN * 1024) + (wave - 1) * TN * 1024;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sp[(j * 16 + r) * 64 + lane] = acc[j][r];
         }
         __syncthreads();                                                // one barrier per round: the slots of round rd are complete
     }
     if (wave != 0) return;
-    {
-        const int rd = rounds;
-        const float* sp = slots + ((rd - 1) & 1) * (3 * TN * 1024);
 #pragma unroll
-        for (int w = 0; w < 3; ++w)
-            if ((rd - 1) * 4 + 1 + w < nk) {
+    for (int w = 0; w < 3; ++w)
+        if ((rounds - 1) * 4 + 1 + w < nk) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) tot[j][r] = tot[j][r] + sp[((w * TN + j) * 16 + r) * 64 + lane];
-            }
-    }
+                for (int r = 0; r < 16; ++r) tot[j][r] = tot[j][r] + slots[((w * TN + j) * 16 + r) * 64 + lane];
+        }
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (EPI == 2) {
+        const int pos = ra_.pos_dev ? *ra_.pos_dev : ra_.descs[0].pos0;
+        const int nrot = (ra_.n_heads + ra_.n_kv) * 64, col0 = bn * 32;
+        if (col0 < nrot) {
+            const int h = bn >> 1, t = (bn & 1) * 16 + (lr & 15);
+            const bool lo = lr < 16;                                     // lanes lr and lr ^ 16 hold the pair (t, t + 32) of head h
+            const float c = ra_.cs[(size_t)pos * 32 + t], sn = ra_.sn[(size_t)pos * 32 + t];
+            const int dim = t + (lo ? 0 : 32);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float mine = tot[0][r], other = __shfl_xor(mine, 16);
+                const float x1 = lo ? mine : other, x2 = lo ? other : mine;
+                const float pa = x1 * (lo ? c : sn), pb = x2 * (lo ? sn : c);      // lo: x1 c, x2 s; hi: x1 s, x2 c
+                const float o = lo ? pa - pb : pa + pb;
+                if (row < M) {
+                    if (h < ra_.n_heads) C[(size_t)row * ldc + h * 64 + dim] = o;
+                    else {
+                        const cz_rope_desc d = ra_.descs[row];
+                        const int kd = (h - ra_.n_heads) * 64 + dim;
+                        if (d.kt_stride) d.k_dst[ra_.kv_off + (size_t)kd * d.kt_stride + pos] = o;
+                        else d.k_dst[ra_.kv_off + (size_t)pos * d.dst_stride + kd] = o;
+                    }
+                }
+            }
+        } else {
+            const int vc = col0 - nrot + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < M) { const cz_rope_desc d = ra_.descs[row]; d.v_dst[ra_.kv_off + (size_t)pos * d.dst_stride + vc] = tot[0][r]; }
+            }
+        }
+        return;
+    }
     if (EPI == 1) {
         const int hcol = (bn * (32 * TN)) / 2 + lr;
 #pragma unroll
@@ -191,9 +242,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mid_kernel(const float* __restric
 }
 
 template <int TN, int EPI>
-static hipError_t launch_mid(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* C, int ldc, const float* R, int ldr, int M, int N, int K) {
+static hipError_t launch_mid(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* C, int ldc, const float* R, int ldr, int M, int N, int K,
+                             mid_rope_args ra = mid_rope_args{}) {
     static bool attr_set = false;
-    const size_t smem = (size_t)(4 * 32 * MID_LDK + 2 * 3 * TN * 1024) * sizeof(float);
+    const size_t smem = (size_t)(4 * 32 * MID_LDK + 3 * TN * 1024 + 4) * sizeof(float);
     auto kern = gemm_mid_kernel<TN, EPI>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -201,7 +253,7 @@ static hipError_t launch_mid(hipStream_t st, const float* A, int lda, const uint
         attr_set = true;
     }
     const int nbx = N / (32 * TN), nby = (M + 31) / 32, nblocks = nbx * nby;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, st, A, lda, Wk, C, ldc, R, ldr, M, N, K, nbx, nblocks);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, st, A, lda, Wk, C, ldc, R, ldr, M, N, K, nbx, nblocks, ra);
     return hipGetLastError();
 }
 // C[M][N] = A . W^T (+ R); Wk = the k2-packed copy of W
@@ -215,4 +267,13 @@ hipError_t cz_launch_gemm_mid_swiglu(hipStream_t st, const float* A, int lda, co
     if (M <= 0) return hipSuccess;
     if (K % 64 != 0 || f % 32 != 0) return hipErrorInvalidValue;
     return launch_mid<2, 1>(st, A, lda, Wk, H, ldh, nullptr, 0, M, 2 * f, K);
+}
+// The fused QKV projection of a lock-step decode step: Q[M][n_heads*64] (rotated) to C, K (rotated) and V to the KV cache rows at *pos_dev.
+// Wk = cz_launch_k2_pack(..., rot_heads = n_heads + n_kv) of the [q | k | v] weight rows.
+hipError_t cz_launch_gemm_mid_qkv(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* Q, int ldq, int M, int K, int n_heads, int n_kv,
+                                  const cz_rope_desc* descs, size_t kv_off, const int* pos_dev, const float* cs, const float* sn) {
+    if (M <= 0) return hipSuccess;
+    if (K % 64 != 0 || !descs || !cs || !sn) return hipErrorInvalidValue;
+    mid_rope_args ra{descs, cs, sn, pos_dev, kv_off, n_heads, n_kv};
+    return launch_mid<1, 2>(st, A, lda, Wk, Q, ldq, nullptr, 0, M, (n_heads + 2 * n_kv) * 64, K, ra);
 }

@@ -74,10 +74,64 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
         *reinterpret_cast<f32x4*>(Y + (size_t)mm * ldy + cc * 4) = o;
     }
 }
+// The same for a FEW HUNDRED rows (one wide lock-step decode group): 4 rows per block instead of 16, so that 512 rows are 128 blocks
+// rather than 32, and the rows pass through LDS once (one global round trip: the kernel is pure latency at this size).
+#define RS_ROWS 4
+#define RS_CH 65                       // floats per 64-chunk in LDS (+1: the nine chain lanes of a row hit different banks)
+#define RS_ROW (16 * RS_CH + 9)        // row stride: 1049 = 25 mod 32
+__global__ __launch_bounds__(256) void rmsnorm_small_kernel(const float* __restrict__ X, int ldx, const uint16_t* __restrict__ w,
+                                                            float* __restrict__ Y, int ldy, int M, int d, float eps) {
+    __shared__ float xs[RS_ROWS * RS_ROW];
+    __shared__ float part[RS_ROWS][17];
+    __shared__ float mv[RS_ROWS];
+    const int tid = threadIdx.x, per_row = d / 4, nch = d / 64, m0 = blockIdx.x * RS_ROWS;
+    for (int i = tid; i < RS_ROWS * per_row; i += 256) {
+        const int rr = i / per_row, cc = i % per_row;
+        if (m0 + rr >= M) break;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(X + (size_t)(m0 + rr) * ldx + cc * 4);
+        float* dst = xs + rr * RS_ROW + (cc >> 4) * RS_CH + (cc & 15) * 4;
+        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+    }
+    __syncthreads();
+    if (tid < RS_ROWS * 16) {
+        const int r = tid >> 4, c = tid & 15;
+        if (m0 + r < M && c < nch) {
+            const float* src = xs + r * RS_ROW + c * RS_CH;
+            float p = 0.0f;
+#pragma unroll 16
+            for (int k = 0; k < 64; ++k) { const float q = src[k] * src[k]; p = p + q; }
+            part[r][c] = p;
+        }
+    }
+    __syncthreads();
+    if (tid < RS_ROWS && m0 + tid < M) {
+        float t = part[tid][0];
+        for (int k = 1; k < nch; ++k) t = t + part[tid][k];
+        mv[tid] = sqrtf(t / (float)d + eps);
+    }
+    __syncthreads();
+    for (int i = tid; i < RS_ROWS * per_row; i += 256) {
+        const int rr = i / per_row, cc = i % per_row;
+        if (m0 + rr >= M) break;
+        const float* src = xs + rr * RS_ROW + (cc >> 4) * RS_CH + (cc & 15) * 4;
+        const uint2 wb = *reinterpret_cast<const uint2*>(w + cc * 4);
+        const float mval = mv[rr];
+        f32x4 o;
+        o[0] = src[0] / mval * cz_bits_f32(wb.x << 16);
+        o[1] = src[1] / mval * cz_bits_f32(wb.x & 0xffff0000u);
+        o[2] = src[2] / mval * cz_bits_f32(wb.y << 16);
+        o[3] = src[3] / mval * cz_bits_f32(wb.y & 0xffff0000u);
+        *reinterpret_cast<f32x4*>(Y + (size_t)(m0 + rr) * ldy + cc * 4) = o;
+    }
+}
 hipError_t cz_launch_rmsnorm(hipStream_t st, const float* X, int ldx, const uint16_t* w, float* Y, int ldy, int M, int d, float eps,
                              const int* row_index) {
     if (M <= 0) return hipSuccess;
     if (d % 64 != 0 || d > 1024) return hipErrorInvalidValue;
+    if (!row_index && M <= 2048) {
+        hipLaunchKernelGGL(rmsnorm_small_kernel, dim3((M + RS_ROWS - 1) / RS_ROWS), dim3(256), 0, st, X, ldx, w, Y, ldy, M, d, eps);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(rmsnorm_kernel, dim3((M + 15) / 16), dim3(256), 0, st, X, ldx, w, Y, ldy, M, d, eps, row_index);
     return hipGetLastError();
 }

@@ -262,10 +262,10 @@ static cz_status build_llama(cz_session* s, const cz_model_desc* desc) {
         auto k2 = [&](const uint16_t* w) { return m.blob_k2 + ((size_t)(w - m.blob) - off0); };
         for (size_t l = 0; l < L; ++l) {
             const LlamaModel::Layer& y = m.L[l];
-            HIPCHK(cz_launch_k2_pack(s->stream, y.wqkv, k2(y.wqkv), d + 2 * kvd, (int)d));
-            HIPCHK(cz_launch_k2_pack(s->stream, y.wo, k2(y.wo), d, (int)d));
-            HIPCHK(cz_launch_k2_pack(s->stream, y.wd, k2(y.wd), d, (int)f));
-            if (y.wgu_i) HIPCHK(cz_launch_k2_pack(s->stream, y.wgu_i, k2(y.wgu), 2 * f, (int)d));     // (the interleaved gate|up rows, in wgu's slot)
+            HIPCHK(cz_launch_k2_pack(s->stream, y.wqkv, k2(y.wqkv), d + 2 * kvd, (int)d, c.n_heads + c.n_kv_heads));   // (RoPE pairs side by side: cz_launch_gemm_mid_qkv)
+            HIPCHK(cz_launch_k2_pack(s->stream, y.wo, k2(y.wo), d, (int)d, 0));
+            HIPCHK(cz_launch_k2_pack(s->stream, y.wd, k2(y.wd), d, (int)f, 0));
+            if (y.wgu_i) HIPCHK(cz_launch_k2_pack(s->stream, y.wgu_i, k2(y.wgu), 2 * f, (int)d, 0));     // (the interleaved gate|up rows, in wgu's slot)
         }
     }
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -442,11 +442,16 @@ static cz_status llama_step_wide(cz_session* s, int B, int pos, int max_nk) {
         const size_t kv_off = (size_t)l * s->kv_layer_stride;
         if (!(s->dbg_skip & 2)) {
             s->prof_begin(PK_DEC_NORM); HIPCHK(cz_launch_rmsnorm(st, x, d, y.ln1, xn, d, B, d, c.rms_eps, nullptr)); s->prof_end(0, (double)B * d * 8);
-            if (mid) HIPCHK(gemm_mid(PK_DEC_GEMM_QKV, xn, d, y.wqkv, qkv, nq, nullptr, nq, d));
-            else HIPCHK(gemm(PK_DEC_GEMM_QKV, xn, d, y.wqkv, qkv, nq, nullptr, nq, d));
-            s->prof_begin(PK_ROPE);                                                        // q rotated in place; k (rotated) and v go to the cache rows at *pos_dev
-            HIPCHK(cz_launch_rope(st, qkv, nq, s->step_roped, B, 1, c.n_heads, c.n_kv_heads, m.rope_cos, m.rope_sin, kv_off, s->pos_dev));
-            s->prof_end(0, (double)B * nq * 8);
+            if (mid) {                                                                     // RoPE and the cache write ride in the projection's epilogue
+                s->prof_begin(PK_DEC_GEMM_QKV);
+                HIPCHK(cz_launch_gemm_mid_qkv(st, xn, d, k2(y.wqkv), qkv, nq, B, d, c.n_heads, c.n_kv_heads, s->step_roped, kv_off, s->pos_dev, m.rope_cos, m.rope_sin));
+                s->prof_end(2.0 * B * (double)nq * d, (double)nq * d * 2 + (double)B * (nq + d) * 4);
+            } else {
+                HIPCHK(gemm(PK_DEC_GEMM_QKV, xn, d, y.wqkv, qkv, nq, nullptr, nq, d));
+                s->prof_begin(PK_ROPE);                                                    // q rotated in place; k (rotated) and v go to the cache rows at *pos_dev
+                HIPCHK(cz_launch_rope(st, qkv, nq, s->step_roped, B, 1, c.n_heads, c.n_kv_heads, m.rope_cos, m.rope_sin, kv_off, s->pos_dev));
+                s->prof_end(0, (double)B * nq * 8);
+            }
         }
         if (!(s->dbg_skip & 1)) {
             s->prof_begin(PK_DEC_ATTN);
