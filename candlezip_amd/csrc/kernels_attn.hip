@@ -197,14 +197,21 @@ __global__ __launch_bounds__(256, (REP * NI <= 48 ? 2 : 1)) void attention_v2_ke
     constexpr bool QLDS = REP * NI >= 48;
     __shared__ __attribute__((aligned(16))) float Qs[QLDS ? REP * 64 * V2_QS : 4];
     float qreg[QLDS ? 1 : REP][16];
-#pragma unroll
-    for (int rt = 0; rt < REP; ++rt) {
+    // (unconditional loads from a clamped row, the select afterwards: a load inside a per-element `valid` branch is waited for on the
+    // spot, i.e. REP x 16 dependent round trips before the block's first MFMA)
+    if (!QLDS || wave == 0) {
         const bool valid = li < rows_here;
-        const float* qp = Q + (size_t)(row_base + (valid ? li : 0)) * ldq + (kvh * REP + rt) * 64 + lg;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const float v = valid ? qp[4 * t] : 0.0f;
-            if (QLDS) { if (wave == 0) Qs[(rt * 64 + lane) * V2_QS + t] = v; } else qreg[rt][t] = v;
+        for (int rt = 0; rt < REP; ++rt) {
+            const float* qp = Q + (size_t)(row_base + (valid ? li : 0)) * ldq + (kvh * REP + rt) * 64 + lg;
+            float raw[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) raw[t] = qp[4 * t];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float v = valid ? raw[t] : 0.0f;
+                if (QLDS) Qs[(rt * 64 + lane) * V2_QS + t] = v; else qreg[rt][t] = v;
+            }
         }
     }
     f32x4 S[NI][REP];

@@ -297,20 +297,18 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
 #endif
         float ef[LMAX];
         float m = -INFINITY;
-        if ((L & 3) == 0 && ((size_t)l & 15) == 0) {             // a lane's chunk is contiguous: 16-B loads (a quarter of the cache-line visits)
+        // Every load unconditional, from a clamped address (entries past the vocabulary are read but never used): a load inside a
+        // per-lane `k < cnt` branch is waited for on the spot, i.e. up to LMAX dependent round trips per row.
+        if ((L & 3) == 0 && ((size_t)l & 15) == 0 && (V & 3) == 0 && V >= 4) {   // a lane's chunk is contiguous: 16-B loads (a quarter of the cache-line visits)
 #pragma unroll
             for (int k = 0; k < LMAX; k += 4) {
-                if (k + 3 < cntA) {
-                    const float4 q = *reinterpret_cast<const float4*>(l + first + k);
-                    ef[k] = q.x; ef[k + 1] = q.y; ef[k + 2] = q.z; ef[k + 3] = q.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (k + j < LMAX && k + j < cntA) ef[k + j] = l[first + k + j];
-                }
+                const int at = FULL ? first + k : (first + k < V - 4 ? first + k : V - 4);
+                const float4 q = *reinterpret_cast<const float4*>(l + at);
+                ef[k] = q.x; ef[k + 1] = q.y; ef[k + 2] = q.z; ef[k + 3] = q.w;
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < LMAX; ++k) if (k < cntA) ef[k] = l[first + k];
+            for (int k = 0; k < LMAX; ++k) ef[k] = l[first + k < V ? first + k : V - 1];
         }
 #pragma unroll
         for (int k = 0; k < LMAX; ++k) if (k < cntA && ef[k] > m) m = ef[k];
@@ -477,7 +475,9 @@ __global__ __launch_bounds__(T_PAR) void xe_prob_kernel(const float* __restrict_
         float ef[LMAX];
         float m = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < LMAX; ++k) if (k < cnt) { ef[k] = l[first + k]; if (ef[k] > m) m = ef[k]; }
+        for (int k = 0; k < LMAX; ++k) ef[k] = l[first + k < V ? first + k : V - 1];      // (unconditional clamped loads, as in cdf_par_kernel)
+#pragma unroll
+        for (int k = 0; k < LMAX; ++k) if (k < cnt && ef[k] > m) m = ef[k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { float y = shfl_xor_f(m, o, lane); m = y > m ? y : m; }
         if (lane == 0) sm.redf[wave] = m;

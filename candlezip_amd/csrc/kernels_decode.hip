@@ -122,11 +122,13 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
         if (wave < nch) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const int arow = m0 + m * 16 + li;
-                const float* xr = a.A + (size_t)(arow < a.M ? arow : 0) * a.lda + wave * 64 + lg;      // natural layout: k = 4t + g
+                // rows past M read row M - 1 (their results are never stored): a load inside a per-element `row < M` branch is waited for on
+                // the spot, sixteen dependent round trips instead of one
+                const int arow = min(m0 + m * 16 + li, a.M - 1);
+                const float* xr = a.A + (size_t)arow * a.lda + wave * 64 + lg;      // natural layout: k = 4t + g
                 f32x4 sacc = f32x4{0, 0, 0, 0};
 #pragma unroll
-                for (int t = 0; t < 16; ++t) xv[m][t] = arow < a.M ? xr[4 * t] : 0.0f;
+                for (int t = 0; t < 16; ++t) xv[m][t] = xr[4 * t];
 #pragma unroll
                 for (int t = 0; t < 16; ++t) sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[m][t] * xv[m][t], 1.0f, sacc, 0, 0, 0);
                 if (li == 0) {                               // C/D: row = 4*lg + r (every column holds the same sum)
@@ -175,8 +177,8 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
         for (int m = 0; m < MT; ++m) {
             tot0[p][m] = 0.0f; tot1[p][m] = 0.0f; res0[p][m] = 0.0f; res1[p][m] = 0.0f;
             if (EPI == EPI_PLAIN && a.R && tid < 256) {
-                const int row = m0 + m * 16 + (tid >> 4);
-                if (row < a.M) { res0[p][m] = a.R[(size_t)row * a.ldc + n0[p] + (tid & 15)]; res1[p][m] = a.R[(size_t)row * a.ldc + n1[p] + (tid & 15)]; }
+                const int row = min(m0 + m * 16 + (tid >> 4), a.M - 1);          // (clamped, unconditional: all residual loads in flight together)
+                res0[p][m] = a.R[(size_t)row * a.ldc + n0[p] + (tid & 15)]; res1[p][m] = a.R[(size_t)row * a.ldc + n1[p] + (tid & 15)];
             }
         }
     for (int c0 = 0; c0 < nch; c0 += NW) {
@@ -194,10 +196,9 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const int arow = m0 + m * 16 + li;
+                const int arow = min(m0 + m * 16 + li, a.M - 1);                  // (clamped: no branch between the row tiles' loads)
                 f32x4 av[4];
-                if (arow >= a.M) { av[0] = av[1] = av[2] = av[3] = f32x4{0, 0, 0, 0}; }
-                else if (NORM == 2) {
+                if (NORM == 2) {
                     const uint16_t* wr = a.normw + c * 64 + lg;
 #pragma unroll
                     for (int t = 0; t < 16; ++t) av[t >> 2][t & 3] = xv[m][t] / mv2[m] * cz_bf16_to_f32(wr[4 * t]);

@@ -149,14 +149,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = bn * BN + (wn * TN + j) * 32 + lr;
+            // the residual values first, all in flight together (rows past M re-read row M - 1): a load + wait inside a per-element
+            // `row < M` branch costs sixteen dependent round trips per tile
+            float rv[16];
+            if (R) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(bm * BM + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1);
+                    rv[r] = R[(size_t)row * ldr + col];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = bm * BM + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < M) {
-                    float v = tot[i][j][r];
-                    if (R) v = v + R[(size_t)row * ldr + col];
-                    C[(size_t)row * ldc + col] = v;
-                }
+                const float v = R ? tot[i][j][r] + rv[r] : tot[i][j][r];
+                if (row < M) C[(size_t)row * ldc + col] = v;
             }
         }
 }

@@ -6,12 +6,12 @@
 // it is cut into ~500+ pieces.  The big-M kernel's tiles (>= 64 x 64, K walked serially) give 54-288 blocks that each walk 9-24 K tiles
 // alone on a CU; dec_gemm_kernel splits K over the waves of a block but re-reads the activations once per 32 output columns and keeps
 // one accumulator chain per operand load.  Here:
-//   * block = ONE 32 x (32 TN) output tile, four waves = four K GROUPS: wave g owns K tiles g, g+4, ...  The M/32 x N/(32 TN) grid is
-//     432 blocks for the 768 x 576 o-projection, 2304 for gate|up.
-//   * the ordered sum of the chunk partials crosses the waves through LDS: every round (4 K tiles) waves 1..3 park their partial tiles
-//     in a slot, ONE barrier, and wave 0 adds them — in K order — to the running total at the START of the next round, then raises an
-//     LDS flag; the other waves check that flag (long since raised: their MFMA chain lies in between) before they overwrite the slot.
-//     One slot set instead of two keeps a gate|up block at 59 KB of LDS, so that two blocks share a CU (three for TN = 1).
+//   * block = ONE 32 x (32 TN) output tile, NW waves = NW K GROUPS: wave g owns K tiles g, g+NW, ...  (NW = 4 by default; see launch_mid).
+//     The M/32 x N/(32 TN) grid is 432 blocks for the 768 x 576 o-projection, 1152 for gate|up.
+//   * the ordered sum of the chunk partials crosses the waves through LDS: every round (NW K tiles) waves 1.. park their partial tiles
+//     on top of their own (spent) activation tile, ONE barrier, and wave 0 adds them — in K order — to the running total; where there
+//     is a next round it does so at its start and then raises an LDS flag, which the other waves await before their next activation
+//     tile replaces the parked partial.  35 KB of LDS per four-wave block: four blocks share a CU (two for gate|up: 180 registers).
 //   * weights are read straight into MFMA operand registers from a copy packed for v_mfma_f32_32x32x2_f32 ("k2": per row and 64-k chunk
 //     the even k, then the odd k, so that lane (n, h) loads its 32 operands k = 2t + h as 64 contiguous bytes); only the activations
 //     pass through LDS (a wave-private 32 x 64 tile: no block barrier for staging).
@@ -56,19 +56,19 @@ __device__ __forceinline__ int mid_xcd_remap(int bid, int nblocks) {    // block
 // EPI = 2 (TN = 1): the fused QKV projection with the head rows reordered by cz_launch_k2_pack(rot_heads = n_heads + n_kv): RoPE
 // (candle_nn::rotary_emb::rope, non-interleaved halves, products rounded separately) in the epilogue; q goes to C, k (rotated) and v
 // straight to the stream's KV cache at *pos_dev — what rope_kernel did in a launch of its own.
-template <int TN, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_mid_kernel(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Wk,
-                                                          float* __restrict__ C, int ldc, const float* __restrict__ R, int ldr,
-                                                          int M, int N, int K, int nbx, int nblocks, mid_rope_args ra_) {
+template <int TN, int EPI, int NW, bool PF>
+__global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : 1) void gemm_mid_kernel(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Wk,
+                                                           float* __restrict__ C, int ldc, const float* __restrict__ R, int ldr,
+                                                           int M, int N, int K, int nbx, int nblocks, mid_rope_args ra_) {
+    static_assert(TN * 1024 <= 32 * MID_LDK, "a wave's partial tiles are parked in its own activation tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* As = smem + wave * (32 * MID_LDK);                            // wave-private activation tile [32][MID_LDK]
-    float* slots = smem + 4 * (32 * MID_LDK);                            // [3][TN][16][64] partial tiles of waves 1..3
-    int* consumed = reinterpret_cast<int*>(slots + 3 * TN * 1024);       // round up to which wave 0 has taken the slots over
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* As = smem + wave * (32 * MID_LDK);                            // wave-private activation tile [32][MID_LDK]; after the chain: this wave's partial tiles
+    int* consumed = reinterpret_cast<int*>(smem + NW * (32 * MID_LDK));  // round up to which wave 0 has taken the partials over
     const int sid = mid_xcd_remap(blockIdx.x, nblocks);
     const int bm = sid / nbx, bn = sid % nbx;
     const int lr = lane & 31, lh = lane >> 5;
-    const int nk = K >> 6, rounds = (nk + 3) >> 2;
+    const int nk = K >> 6, rounds = (nk + NW - 1) / NW;
     const int srow = lane >> 3, sg = lane & 7;                           // staging: 8 rows x 8 k-groups per pass, 4 passes
 
     f32x4 ra[4][2];
@@ -76,11 +76,11 @@ __global__ __launch_bounds__(256, 2) void gemm_mid_kernel(const float* __restric
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int row = bm * 32 + p * 8 + srow;
-            if (row < M) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(A + (size_t)row * lda + kt * 64 + sg * 8);
-                ra[p][0] = src[0]; ra[p][1] = src[1];
-            } else { ra[p][0] = f32x4{0, 0, 0, 0}; ra[p][1] = f32x4{0, 0, 0, 0}; }
+            // rows past M read row M - 1 (no branch: a branch per pass serialises the passes' round trips); an output row depends on its own
+            // activation row only and the epilogues store rows < M only
+            const int row = min(bm * 32 + p * 8 + srow, M - 1);
+            const f32x4* src = reinterpret_cast<const f32x4*>(A + (size_t)row * lda + kt * 64 + sg * 8);
+            ra[p][0] = src[0]; ra[p][1] = src[1];
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -98,41 +98,54 @@ __global__ __launch_bounds__(256, 2) void gemm_mid_kernel(const float* __restric
             *reinterpret_cast<f32x4*>(dst + 4) = f32x4{ra[p][0][1], ra[p][0][3], ra[p][1][1], ra[p][1][3]};
         }
     };
-
-    f32x16 tot[TN];
+    // a wave's partial tiles in LDS: [TN][4][64 lanes][4] floats (b128 per lane and register quad)
+    auto add_partials = [&](f32x16* tot, int first_chunk) {             // wave 0: + the partials of waves 1..NW-1 (chunks first_chunk + w), in K order
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+        for (int w = 1; w < NW; ++w)
+            if (first_chunk + w < nk) {
+                const float* sp = smem + w * (32 * MID_LDK);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tot[j][r] = 0.0f;
-    if (wave < nk) load_tile(wave);
-    for (int rd = 0; rd < rounds; ++rd) {
-        const int kt = rd * 4 + wave;
-        if (wave == 0) {
-            // chunk partials of the previous round's waves 1..3, in K order (complete since the barrier that ended that round)
-            if (rd > 0) {
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int w = 0; w < 3; ++w)
-                    if ((rd - 1) * 4 + 1 + w < nk) {
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(sp + ((j * 4 + q) * 64 + lane) * 4);
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) tot[j][r] = tot[j][r] + slots[((w * TN + j) * 16 + r) * 64 + lane];
+                        for (int e = 0; e < 4; ++e) tot[j][4 * q + e] = tot[j][4 * q + e] + v[e];
                     }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) __hip_atomic_store(consumed, rd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    f32x16 tot[TN];
+    if (PF) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot[j][r] = 0.0f;
+    }
+    if (wave < nk) load_tile(wave);
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int kt = rd * NW + wave;
+        if (PF) {
+            if (wave == 0) {
+                if (rd > 0) add_partials(tot, (rd - 1) * NW);             // (complete since the barrier that ended the previous round)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(consumed, rd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (rd > 0 && kt < nk) {                              // this wave's tile is about to replace its parked partial: wave 0 must have it
+                while (__hip_atomic_load(consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rd) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
         }
-        f32x16 acc[TN];
         if (kt < nk) {
+            store_tile();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0xc07f);                        // this wave's LDS writes are visible to its own lanes (lgkmcnt(0))
             unsigned wb[TN][16];
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { wb[j][4 * q] = rb[j][q].x; wb[j][4 * q + 1] = rb[j][q].y; wb[j][4 * q + 2] = rb[j][q].z; wb[j][4 * q + 3] = rb[j][q].w; }
-            store_tile();
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_s_waitcnt(0xc07f);                        // this wave's LDS writes are visible to its own lanes (lgkmcnt(0))
-            if (kt + 4 < nk) load_tile(kt + 4);                         // next tile of this wave in flight under the MFMA chain
+            if (PF && kt + NW < nk) load_tile(kt + NW);                 // next tile of this wave in flight under the MFMA chain
+            f32x16 acc[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -152,35 +165,24 @@ __global__ __launch_bounds__(256, 2) void gemm_mid_kernel(const float* __restric
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_s_waitcnt(0xc07f);                        // (the reads of As are done before the next round overwrites it)
+            __builtin_amdgcn_s_waitcnt(0xc07f);                        // (the reads of As are done before the partial goes on top of it)
             if (wave == 0) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) tot[j][r] = rd == 0 ? acc[j][r] : tot[j][r] + acc[j][r];
+                    for (int r = 0; r < 16; ++r) tot[j][r] = (!PF || rd == 0) ? acc[j][r] : tot[j][r] + acc[j][r];
             } else {
-                if (rd > 0) {                                           // wave 0 has taken over the previous round's partials (it did so a whole MFMA chain ago)
-                    while (__hip_atomic_load(consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rd) __builtin_amdgcn_s_sleep(1);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                }
-                float* sp = slots + (wave - 1) * TN * 1024;
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sp[(j * 16 + r) * 64 + lane] = acc[j][r];
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<f32x4*>(As + ((j * 4 + q) * 64 + lane) * 4) = f32x4{acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
             }
         }
-        __syncthreads();                                                // one barrier per round: the slots of round rd are complete
+        __syncthreads();                                                // one barrier per round: the partials of round rd are complete
     }
     if (wave != 0) return;
-#pragma unroll
-    for (int w = 0; w < 3; ++w)
-        if ((rounds - 1) * 4 + 1 + w < nk) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tot[j][r] = tot[j][r] + slots[((w * TN + j) * 16 + r) * 64 + lane];
-        }
+    add_partials(tot, (rounds - 1) * NW);
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     if (EPI == 2) {
         const int pos = ra_.pos_dev ? *ra_.pos_dev : ra_.descs[0].pos0;
@@ -229,32 +231,46 @@ __global__ __launch_bounds__(256, 2) void gemm_mid_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = bn * (32 * TN) + j * 32 + lr;
+        float rv[16];                                                     // (all residual loads in flight together: see gemm_bf16w_kernel)
+        if (R) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = R[(size_t)min(bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1) * ldr + col];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row < M) {
-                float v = tot[j][r];
-                if (R) v = v + R[(size_t)row * ldr + col];
-                C[(size_t)row * ldc + col] = v;
-            }
+            const float v = R ? tot[j][r] + rv[r] : tot[j][r];
+            if (row < M) C[(size_t)row * ldc + col] = v;
         }
     }
 }
 
-template <int TN, int EPI>
-static hipError_t launch_mid(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* C, int ldc, const float* R, int ldr, int M, int N, int K,
-                             mid_rope_args ra = mid_rope_args{}) {
+template <int TN, int EPI, int NW, bool PF>
+static hipError_t launch_mid_nw(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* C, int ldc, const float* R, int ldr, int M, int N, int K,
+                                mid_rope_args ra) {
     static bool attr_set = false;
-    const size_t smem = (size_t)(4 * 32 * MID_LDK + 3 * TN * 1024 + 4) * sizeof(float);
-    auto kern = gemm_mid_kernel<TN, EPI>;
+    const size_t smem = (size_t)(NW * 32 * MID_LDK + 4) * sizeof(float);
+    auto kern = gemm_mid_kernel<TN, EPI, NW, PF>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int nbx = N / (32 * TN), nby = (M + 31) / 32, nblocks = nbx * nby;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, st, A, lda, Wk, C, ldc, R, ldr, M, N, K, nbx, nblocks, ra);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NW * 64), smem, st, A, lda, Wk, C, ldc, R, ldr, M, N, K, nbx, nblocks, ra);
     return hipGetLastError();
+}
+// K groups per block.  Measured on 512-row groups (profiles/r02_microbench/call24_*): four groups with operand prefetch beat a wave per
+// 64-chunk (nine waves, one round for K = 576: +8 % step time) — a block's latency is dominated by its first, cold operand load and by
+// the 0.85 us dependent MFMA chain per chunk, and four-wave blocks pack four to a CU where nine-wave blocks pack one or two.
+int g_mid_nw = 4;             // tuning knob (cz_debug_set "mid_nw"): 4 / 8 = that many K groups with operand prefetch, 0 = nine (K <= 576, one round) or twelve
+template <int TN, int EPI>
+static hipError_t launch_mid(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* C, int ldc, const float* R, int ldr, int M, int N, int K,
+                             mid_rope_args ra = mid_rope_args{}) {
+    if (g_mid_nw == 8) return launch_mid_nw<TN, EPI, 8, true>(st, A, lda, Wk, C, ldc, R, ldr, M, N, K, ra);
+    if (g_mid_nw != 0) return launch_mid_nw<TN, EPI, 4, true>(st, A, lda, Wk, C, ldc, R, ldr, M, N, K, ra);
+    if (K / 64 <= 9) return launch_mid_nw<TN, EPI, 9, false>(st, A, lda, Wk, C, ldc, R, ldr, M, N, K, ra);
+    return launch_mid_nw<TN, EPI, TN == 1 ? 12 : 8, true>(st, A, lda, Wk, C, ldc, R, ldr, M, N, K, ra);   // (two accumulator tiles: 168 registers do not hold a 12-wave block's third wave per SIMD)
 }
 // C[M][N] = A . W^T (+ R); Wk = the k2-packed copy of W
 hipError_t cz_launch_gemm_mid(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* C, int ldc, const float* R, int ldr, int M, int N, int K) {
