@@ -173,10 +173,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #define V2_VS 80
 #define V2_QS 20                        // floats per lane of the LDS copy of the Q operand (16 + 4: the four ds_read_b128 of a wave hit distinct banks)
 template <int REP, int NI>
-__global__ __launch_bounds__(256, (REP * NI <= 48 ? 2 : 1)) void attention_v2_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
+__global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1)) void attention_v2_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
                                                               const cz_seq_desc* __restrict__ descs, size_t kv_off, const int* __restrict__ pos_dev) {
-    __shared__ __attribute__((aligned(16))) float stage[64 * V2_VS];      // K tile (stride 68) or V tile (stride 80)
-    __shared__ __attribute__((aligned(16))) float Et[REP * 16 * V2_KS];   // e / p tile of the current chunk, [slot][key]
+    // DB: K/V tile and e/p tile double-buffered, so that a chunk costs ONE block barrier per phase instead of two (the kernel's waves spend
+    // about half their cycles waiting: two waves per SIMD hide little).  Where three blocks share a CU (REP * NI <= 24) the LDS is for them.
+    constexpr bool DB = REP * NI > 24;
+    __shared__ __attribute__((aligned(16))) float stage_[(DB ? 2 : 1) * 64 * V2_VS];   // K tile (stride 68) or V tile (stride 80)
+    __shared__ __attribute__((aligned(16))) float Et_[REP * 16 * V2_KS];               // e / p tile of a chunk, [slot][key]
     __shared__ float csum[REP * 16][NI + 1];
     __shared__ float wred[4][REP * 16];
     __shared__ float rsum[REP * 16];
@@ -193,9 +196,13 @@ __global__ __launch_bounds__(256, (REP * NI <= 48 ? 2 : 1)) void attention_v2_ke
     const int row_base = sd.row0 + tile * 16;
     // A operand of QK^T: lane (i = li, g = lg) holds Q[row i][head][d = 4t + g].  Where the score tiles alone fill most of the register
     // file (REP * NI >= 48: 192 VGPRs of S) the operand lives in LDS instead — lane-contiguous, so a chunk re-reads it with four
-    // ds_read_b128 per head — and the kernel stays under 256 VGPRs without scratch (it spilled 64 registers per lane before).
-    constexpr bool QLDS = REP * NI >= 48;
+    // ds_read_b128 per head — and the kernel stays under 256 VGPRs without scratch (it spilled 64 registers per lane before).  The
+    // 512-key variant of the re-prime (REP * NI = 24) does the same to fit 168 registers: three blocks per CU instead of two.
+    constexpr bool QLDS = REP * NI >= 24;
+    static_assert(!DB || (QLDS && REP * 64 * V2_QS >= REP * 16 * V2_KS), "the second e/p tile lives where the Q operand was (dead after phase 1)");
     __shared__ __attribute__((aligned(16))) float Qs[QLDS ? REP * 64 * V2_QS : 4];
+    auto stage_of = [&](int c) { return stage_ + (DB ? (c & 1) * (64 * V2_VS) : 0); };
+    auto et_of = [&](int c) { return (DB && (c & 1)) ? Qs : Et_; };
     float qreg[QLDS ? 1 : REP][16];
     // (unconditional loads from a clamped row, the select afterwards: a load inside a per-element `valid` branch is waited for on the
     // spot, i.e. REP x 16 dependent round trips before the block's first MFMA)
@@ -251,6 +258,7 @@ __global__ __launch_bounds__(256, (REP * NI <= 48 ? 2 : 1)) void attention_v2_ke
 #pragma unroll
         for (int rt = 0; rt < REP; ++rt) S[c][rt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         if (c < nch) {
+            float* stage = stage_of(c);
 #pragma unroll
             for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(stage + ((tid >> 4) + 16 * p) * V2_KS + (tid & 15) * 4) = pre[p];
             __syncthreads();
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(256, (REP * NI <= 48 ? 2 : 1)) void attention_v2_ke
                     S[c][rt][r] = v;
                 }
             }
-            __syncthreads();
+            if (!DB) __syncthreads();                                   // (DB: the next chunk goes to the other buffer; the one after that is past the next barrier)
         }
     }
     load_v(0, pre);                                                    // first V chunk: in flight during the softmax phases
@@ -317,6 +325,7 @@ __global__ __launch_bounds__(256, (REP * NI <= 48 ? 2 : 1)) void attention_v2_ke
 #pragma unroll
     for (int c = 0; c < NI; ++c) {
         if (c < nch) {
+            float* Et = et_of(c);
 #pragma unroll
             for (int rt = 0; rt < REP; ++rt)
 #pragma unroll
@@ -339,9 +348,10 @@ __global__ __launch_bounds__(256, (REP * NI <= 48 ? 2 : 1)) void attention_v2_ke
                     for (int r = 0; r < 4; ++r) csum[wave * 16 + 4 * lg + r][c] = sacc[r];
                 }
             }
-            __syncthreads();
+            if (!DB) __syncthreads();
         }
     }
+    if (DB) __syncthreads();                                            // csum complete
     if (tid < REP * 16) {
         float t = csum[tid][0];
         for (int c = 1; c < nch; ++c) t = t + csum[tid][c];
@@ -360,6 +370,8 @@ __global__ __launch_bounds__(256, (REP * NI <= 48 ? 2 : 1)) void attention_v2_ke
 #pragma unroll
     for (int c = 0; c < NI; ++c) {
         if (c < nch) {
+            float* Et = et_of(c);
+            float* stage = stage_of(c);
 #pragma unroll
             for (int rt = 0; rt < REP; ++rt)
 #pragma unroll
@@ -388,7 +400,7 @@ __global__ __launch_bounds__(256, (REP * NI <= 48 ? 2 : 1)) void attention_v2_ke
 #pragma unroll
                     for (int r = 0; r < 4; ++r) tot[rt][r] = tot[rt][r] + acc[r];
             }
-            __syncthreads();
+            if (!DB) __syncthreads();
         }
     }
 #pragma unroll
