@@ -246,7 +246,7 @@ def main():
     ap.add_argument("--lane-streams", type=int, default=512, help="streams per lock-step group (>= 256: the wide-group decode step)")
     ap.add_argument("--sample-tokens", type=int, default=17408, help="tokens per stream (a 64 KiB enwik8 sample is ~17.4k SmolLM2 tokens)")
     ap.add_argument("--window", type=int, default=512, help="tokens per stream and step; a multiple of the re-prime interval, so that no window re-computes another one's history rows")
-    ap.add_argument("--overlap", type=int, default=0, help="1: the compress half of a step runs on a forked session WHILE the decompress half runs")
+    ap.add_argument("--overlap", type=int, default=1, help="1 (default): the compress half of a step runs on a forked session WHILE the decompress half runs (+3-4 %: MFMA-bound beside HBM-bound); 0: one after the other, so that the two halves are timed alone")
     ap.add_argument("--no-graph", action="store_true", help="launch the decode step eagerly (one AQL packet per submission: for rocprofv3 --pmc)")
     ap.add_argument("--no-events", action="store_true", help="no HIP-event timing inside the timed region (for rocprofv3 --pmc)")
     ap.add_argument("--step-sync", action="store_true", help="with --no-graph: synchronise after every decode step, so that launches never queue up (rocprofv3 --pmc, DESIGN.md §9)")
@@ -398,6 +398,8 @@ def main():
             "generations_verified": pipe.verified,
             "compress_tokens_per_s_rank0": round(tok / te, 1) if te else None,
             "decompress_tokens_per_s_rank0": round(tok / td, 1) if td else None,
+            "halves_note": ("the two halves of a step ran at the same time and shared the device: each rate is lower than alone (--overlap 0 times them alone)"
+                            if args.overlap else "the two halves of a step ran one after the other"),
             "roofline": roof,
         }
         if prof_all and dominant != "dec_attn_kernel":

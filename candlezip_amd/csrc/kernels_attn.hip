@@ -169,6 +169,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // REP x 16x16 score tiles in registers for all NI chunks (NI*REP*4 VGPRs, one wave per SIMD); in the P.V phase wave w owns
 // output columns 16w..16w+15 for every chunk in order.  LDS holds only one K/V tile and one e/p tile (35 KB).
 // QK^T is computed once; exact two-sweep softmax (max, then e and canonical row sums, then p = e/sum).
+#ifdef CZ_ATTN_DBG     // tuning build (make attn_dbg): parts of the kernel switched off by a device-side mask, to time what is left (results are wrong)
+__device__ int g_attn_dbg_dev;
+extern "C" void cz_debug_attn_dbg(int v) { hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbg_dev), &v, sizeof v); }
+#define ADBG(bit) (dbg & (bit))
+#else
+#define ADBG(bit) false
+#endif
 #define V2_KS 68
 #define V2_VS 80
 #define V2_QS 20                        // floats per lane of the LDS copy of the Q operand (16 + 4: the four ds_read_b128 of a wave hit distinct banks)
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
                                                               const cz_seq_desc* __restrict__ descs, size_t kv_off, const int* __restrict__ pos_dev) {
     // DB: K/V tile and e/p tile double-buffered, so that a chunk costs ONE block barrier per phase instead of two (the kernel's waves spend
     // about half their cycles waiting: two waves per SIMD hide little).  Where three blocks share a CU (REP * NI <= 24) the LDS is for them.
-    constexpr bool DB = REP * NI > 24;
+    constexpr bool DB = REP * NI > 24 && NI <= 24;      // (NI = 32: the unrolled body outgrows the unroller and the score tiles would land in scratch)
     __shared__ __attribute__((aligned(16))) float stage_[(DB ? 2 : 1) * 64 * V2_VS];   // K tile (stride 68) or V tile (stride 80)
     __shared__ __attribute__((aligned(16))) float Et_[REP * 16 * V2_KS];               // e / p tile of a chunk, [slot][key]
     __shared__ float csum[REP * 16][NI + 1];
@@ -194,6 +201,9 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const int row_base = sd.row0 + tile * 16;
+#ifdef CZ_ATTN_DBG
+    const int dbg = g_attn_dbg_dev;
+#endif
     // A operand of QK^T: lane (i = li, g = lg) holds Q[row i][head][d = 4t + g].  Where the score tiles alone fill most of the register
     // file (REP * NI >= 48: 192 VGPRs of S) the operand lives in LDS instead — lane-contiguous, so a chunk re-reads it with four
     // ds_read_b128 per head — and the kernel stays under 256 VGPRs without scratch (it spilled 64 registers per lane before).  The
@@ -225,6 +235,7 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
     // K / V chunk loads: one block per CU and one wave per SIMD leave nothing else to hide a miss behind, so the NEXT chunk's four
     // 16-B pieces per thread are fetched into registers while the current chunk's MFMAs run
     auto load_k = [&](int c, f32x4* out) {
+        if (ADBG(32)) { out[0] = out[1] = out[2] = out[3] = f32x4{0.5f, 0.25f, 0.125f, 1.0f}; return; }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int key = (tid >> 4) + 16 * p, q4 = tid & 15;
@@ -240,6 +251,7 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
         }
     };
     auto load_v = [&](int c, f32x4* out) {
+        if (ADBG(32)) { out[0] = out[1] = out[2] = out[3] = f32x4{0.5f, 0.25f, 0.125f, 1.0f}; return; }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int key = (tid >> 4) + 16 * p, q4 = tid & 15;
@@ -273,7 +285,8 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
 #pragma unroll
             for (int rt = 0; rt < REP; ++rt) {
                 f32x4 acc = f32x4{0, 0, 0, 0};
-                if (QLDS) {                                                 // operands in pieces of four k-steps: 8 live registers instead of 32
+                if (ADBG(1)) { acc[0] = (float)key; }
+                else if (QLDS) {                                            // operands in pieces of four k-steps: 8 live registers instead of 32
                     const f32x4* qp4 = reinterpret_cast<const f32x4*>(Qs + (rt * 64 + lane) * V2_QS);
 #pragma unroll
                     for (int t4 = 0; t4 < 4; ++t4) {
@@ -322,36 +335,41 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
             gmax[rt][r] = m;
         }
     // ---- phase 3: e = exp(s - max); canonical row sums (sequential inside a 64-key chunk, chunks left to right)
+    // canonical chunk sum of a head's 16 rows (acc = acc + e_k, k ascending from 0) on the MFMA: with B = 1 the chain fma(e_k, 1, acc) rounds
+    // e_k + acc once — the same bits as the add — and sixteen 16x16x4 steps replace 64 dependent LDS reads + adds
+    auto exp_elem = [&](int c, int rt, int r, float* Et) {
+        const int qr = 4 * lg + r;
+        const float e = qr < rows_here ? (ADBG(2) ? S[c][rt][r] - gmax[rt][r] : cz_expf(S[c][rt][r] - gmax[rt][r])) : 0.0f;
+        S[c][rt][r] = e;
+        Et[(rt * 16 + qr) * V2_KS + wave * 16 + li] = e;
+    };
+    // (Issuing chunk c's sixteen dependent sum MFMAs between the exponentials of chunk c + 1 was tried: the longer live ranges cost 24
+    // spilled registers at <3,16> and the kernel got 6 % slower, call27.)
+    {
 #pragma unroll
-    for (int c = 0; c < NI; ++c) {
-        if (c < nch) {
-            float* Et = et_of(c);
+        for (int c = 0; c < NI; ++c) {
+            if (c < nch) {
+                float* Et = et_of(c);
 #pragma unroll
-            for (int rt = 0; rt < REP; ++rt)
+                for (int rt = 0; rt < REP; ++rt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int qr = 4 * lg + r;
-                    const float e = qr < rows_here ? cz_expf(S[c][rt][r] - gmax[rt][r]) : 0.0f;
-                    S[c][rt][r] = e;
-                    Et[(rt * 16 + qr) * V2_KS + wave * 16 + li] = e;
+                    for (int r = 0; r < 4; ++r) exp_elem(c, rt, r, Et);
+                __syncthreads();
+                if (wave < REP && !ADBG(4)) {
+                    const float* pa = Et + (wave * 16 + li) * V2_KS + lg;            // A[i = li][k = 4t + lg] = e[row][key]
+                    f32x4 sacc = f32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * t], 1.0f, sacc, 0, 0, 0);
+                    if (li == 0) {                                                    // C/D: row = 4*lg + r; every column holds the same sum
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) csum[wave * 16 + 4 * lg + r][c] = sacc[r];
+                    }
                 }
-            __syncthreads();
-            if (wave < REP) {
-                // canonical chunk sum of head `wave`'s 16 rows (acc = acc + e_k, k ascending from 0) on the MFMA: with B = 1 the chain
-                // fma(e_k, 1, acc) rounds e_k + acc once — the same bits as the add — and sixteen 16x16x4 steps replace 64 dependent LDS reads + adds
-                const float* pa = Et + (wave * 16 + li) * V2_KS + lg;            // A[i = li][k = 4t + lg] = e[row][key]
-                f32x4 sacc = f32x4{0, 0, 0, 0};
-#pragma unroll
-                for (int t = 0; t < 16; ++t) sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * t], 1.0f, sacc, 0, 0, 0);
-                if (li == 0) {                                                    // C/D: row = 4*lg + r; every column holds the same sum
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) csum[wave * 16 + 4 * lg + r][c] = sacc[r];
-                }
+                if (!DB) __syncthreads();
             }
-            if (!DB) __syncthreads();
         }
+        if (DB) __syncthreads();                                        // csum complete
     }
-    if (DB) __syncthreads();                                            // csum complete
     if (tid < REP * 16) {
         float t = csum[tid][0];
         for (int c = 1; c < nch; ++c) t = t + csum[tid][c];
@@ -377,7 +395,7 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qr = 4 * lg + r;
-                    Et[(rt * 16 + qr) * V2_KS + wave * 16 + li] = qr < rows_here ? S[c][rt][r] / rs[rt][r] : 0.0f;
+                    Et[(rt * 16 + qr) * V2_KS + wave * 16 + li] = qr < rows_here ? (ADBG(8) ? S[c][rt][r] : S[c][rt][r] / rs[rt][r]) : 0.0f;
                 }
 #pragma unroll
             for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(stage + ((tid >> 4) + 16 * p) * V2_VS + (tid & 15) * 4) = pre[p];
@@ -393,6 +411,8 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
             for (int rt = 0; rt < REP; ++rt) {
                 const float* pa = Et + (rt * 16 + li) * V2_KS + lg;          // A[i = li][k = 4t + lg] = P[row][key]
                 f32x4 acc = f32x4{0, 0, 0, 0};
+                if (ADBG(16)) acc[0] = pa[0];
+                else
 #pragma unroll
                 for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * t], QLDS ? vbp[4 * t * V2_VS] : vb[t], acc, 0, 0, 0);
                 if (c == 0) tot[rt] = acc;

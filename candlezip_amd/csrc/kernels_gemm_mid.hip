@@ -9,9 +9,9 @@
 //   * block = ONE 32 x (32 TN) output tile, NW waves = NW K GROUPS: wave g owns K tiles g, g+NW, ...  (NW = 4 by default; see launch_mid).
 //     The M/32 x N/(32 TN) grid is 432 blocks for the 768 x 576 o-projection, 1152 for gate|up.
 //   * the ordered sum of the chunk partials crosses the waves through LDS: every round (NW K tiles) waves 1.. park their partial tiles
-//     on top of their own (spent) activation tile, ONE barrier, and the round's last wave adds them — in K order, its own last — to the
-//     running total; where there is a next round it does so at its start and then raises an LDS flag, which the other waves await before
-//     their next activation tile replaces the parked partial.  35 KB of LDS per four-wave block: four blocks share a CU (two for gate|up: 180 registers).
+//     on top of their own (spent) activation tile, ONE barrier, and wave 0 adds them — in K order — to the running total; where there
+//     is a next round it does so at its start and then raises an LDS flag, which the other waves await before their next activation
+//     tile replaces the parked partial.  35 KB of LDS per four-wave block: four blocks share a CU (two for gate|up: 180 registers).
 //   * weights are read straight into MFMA operand registers from a copy packed for v_mfma_f32_32x32x2_f32 ("k2": per row and 64-k chunk
 //     the even k, then the odd k, so that lane (n, h) loads its 32 operands k = 2t + h as 64 contiguous bytes); only the activations
 //     pass through LDS (a wave-private 32 x 64 tile: no block barrier for staging).
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : 1) void gemm_mi
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* As = smem + wave * (32 * MID_LDK);                            // wave-private activation tile [32][MID_LDK]; after the chain: this wave's partial tiles
-    int* consumed = reinterpret_cast<int*>(smem + NW * (32 * MID_LDK));  // round up to which the summing wave has taken the partials over
+    int* consumed = reinterpret_cast<int*>(smem + NW * (32 * MID_LDK));  // round up to which wave 0 has taken the partials over
     const int sid = mid_xcd_remap(blockIdx.x, nblocks);
     const int bm = sid / nbx, bn = sid % nbx;
     const int lr = lane & 31, lh = lane >> 5;
@@ -98,15 +98,11 @@ __global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : 1) void gemm_mi
             *reinterpret_cast<f32x4*>(dst + 4) = f32x4{ra[p][0][1], ra[p][0][3], ra[p][1][1], ra[p][1][3]};
         }
     };
-    // The LAST wave of a round sums: it owns the fewest K tiles (K = 576: tiles 3 and 7 against wave 0's 0, 4, 8), so the ordered sum and
-    // the epilogue (sixteen SiLUs per lane for gate|up) land on the least loaded SIMD.  A wave's partial tiles in LDS: [TN][4][64 lanes][4]
-    // floats (b128 per lane and register quad).
-    constexpr int SW = NW - 1;
-    f32x16 tot[TN], acc[TN];
-    auto sum_round = [&](int r) {                                       // chunks r NW .. r NW + NW - 1 in K order: the parked partials, then this wave's own
+    // a wave's partial tiles in LDS: [TN][4][64 lanes][4] floats (b128 per lane and register quad)
+    auto add_partials = [&](f32x16* tot, int first_chunk) {             // wave 0: + the partials of waves 1..NW-1 (chunks first_chunk + w), in K order
 #pragma unroll
-        for (int w = 0; w < SW; ++w)
-            if (r * NW + w < nk) {
+        for (int w = 1; w < NW; ++w)
+            if (first_chunk + w < nk) {
                 const float* sp = smem + w * (32 * MID_LDK);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
@@ -114,26 +110,27 @@ __global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : 1) void gemm_mi
                     for (int q = 0; q < 4; ++q) {
                         const f32x4 v = *reinterpret_cast<const f32x4*>(sp + ((j * 4 + q) * 64 + lane) * 4);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) tot[j][4 * q + e] = (r == 0 && w == 0) ? v[e] : tot[j][4 * q + e] + v[e];
+                        for (int e = 0; e < 4; ++e) tot[j][4 * q + e] = tot[j][4 * q + e] + v[e];
                     }
             }
-        if (r * NW + SW < nk) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) tot[j][e] = (NW == 1 && r == 0) ? acc[j][e] : tot[j][e] + acc[j][e];
-        }
     };
-    if (wave == SW && lane == 0) __hip_atomic_store(consumed, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (before the first barrier)
+
+    f32x16 tot[TN];
+    if (PF) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot[j][r] = 0.0f;
+    }
     if (wave < nk) load_tile(wave);
     for (int rd = 0; rd < rounds; ++rd) {
         const int kt = rd * NW + wave;
-        if (PF && rd > 0) {
-            if (wave == SW) {
-                sum_round(rd - 1);                                        // (the partials are complete since the barrier that ended the previous round)
+        if (PF) {
+            if (wave == 0) {
+                if (rd > 0) add_partials(tot, (rd - 1) * NW);             // (complete since the barrier that ended the previous round)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __hip_atomic_store(consumed, rd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else if (kt < nk) {                                        // this wave's tile is about to replace its parked partial: the summing wave must have it
+            } else if (rd > 0 && kt < nk) {                              // this wave's tile is about to replace its parked partial: wave 0 must have it
                 while (__hip_atomic_load(consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rd) __builtin_amdgcn_s_sleep(1);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
@@ -148,6 +145,7 @@ __global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : 1) void gemm_mi
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { wb[j][4 * q] = rb[j][q].x; wb[j][4 * q + 1] = rb[j][q].y; wb[j][4 * q + 2] = rb[j][q].z; wb[j][4 * q + 3] = rb[j][q].w; }
             if (PF && kt + NW < nk) load_tile(kt + NW);                 // next tile of this wave in flight under the MFMA chain
+            f32x16 acc[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -168,7 +166,12 @@ __global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : 1) void gemm_mi
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_s_waitcnt(0xc07f);                        // (the reads of As are done before the partial goes on top of it)
-            if (wave != SW) {
+            if (wave == 0) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tot[j][r] = (!PF || rd == 0) ? acc[j][r] : tot[j][r] + acc[j][r];
+            } else {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -178,8 +181,8 @@ __global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : 1) void gemm_mi
         }
         __syncthreads();                                                // one barrier per round: the partials of round rd are complete
     }
-    if (wave != SW) return;
-    sum_round(rounds - 1);
+    if (wave != 0) return;
+    add_partials(tot, (rounds - 1) * NW);
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     if (EPI == 2) {
         const int pos = ra_.pos_dev ? *ra_.pos_dev : ra_.descs[0].pos0;
@@ -258,7 +261,8 @@ static hipError_t launch_mid_nw(hipStream_t st, const float* A, int lda, const u
     return hipGetLastError();
 }
 // K groups per block.  Measured on 512-row groups (profiles/r02_microbench/call24_*): four groups with operand prefetch beat a wave per
-// 64-chunk (nine waves, one round for K = 576: +8 % step time) — a block's latency is dominated by its first, cold operand load and by
+// 64-chunk (nine waves, one round for K = 576: +8 % step time) and summing on the round's last wave instead of its first (the wave with
+// the fewest K tiles: +2 %, call26) — a block's latency is dominated by its first, cold operand load and by
 // the 0.85 us dependent MFMA chain per chunk, and four-wave blocks pack four to a CU where nine-wave blocks pack one or two.
 int g_mid_nw = 4;             // tuning knob (cz_debug_set "mid_nw"): 4 / 8 = that many K groups with operand prefetch, 0 = nine (K <= 576, one round) or twelve
 template <int TN, int EPI>
