@@ -255,6 +255,8 @@ def main():
     ap.add_argument("--context", type=int, default=512)
     ap.add_argument("--reprime-interval", type=int, default=512)
     ap.add_argument("--cpu-sample", type=int, default=640, help="tokens of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--dec-priority", type=int, default=0, help="HIP stream priority of the decode lanes: -1 = high, 0 = normal")
+    ap.add_argument("--enc-priority", type=int, default=0, help="HIP stream priority of the forked compress session (--overlap 1): 1 = low, 0 = normal, -1 = high")
     ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE", help="library tuning knob (cz_debug_set)")
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check only)")
     args = ap.parse_args()
@@ -291,7 +293,11 @@ def main():
         sess.debug_set(k, int(v))
     # work list: world x streams independent files; LPT over the ranks (equal sizes -> `streams` per rank), no data-path collective
     mine = lpt_assign([args.sample_tokens] * (world * args.streams), world)[rank]
+    if args.dec_priority:
+        sess.debug_set("stream_priority", args.dec_priority)
     enc_sess = sess.fork() if args.overlap else None
+    if enc_sess is not None and args.enc_priority:
+        enc_sess.debug_set("stream_priority", args.enc_priority)     # the throughput-bound encoder yields to the latency-bound decode lanes
     pipe = SelfTestPipeline(cz, sess, mine, args.sample_tokens, args.window, cfg.vocab, args.context, args.reprime_interval, enc_sess)
     note(f"rank {rank}/{world}: session open, {len(mine)} streams x {args.sample_tokens} tokens, {groups} lanes x {per_lane}, window {args.window}")
     if os.environ.get("CZ_DUMP_MAPS"):      # diagnostics: the address map of this process (to symbolise a native stack trace afterwards)

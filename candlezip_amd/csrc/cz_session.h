@@ -66,6 +66,7 @@ struct cz_session {
     size_t max_batch_rows = 98304, logit_batch_rows = 8192;
     int force_big_gemm = 0, serial_cdf = 0, decode_v1 = 0, no_graph = 0, fuse_norm = 0, step_sync = 0, dbg_skip = 0, wide_min_streams = 256, wide_mode = 3;
     hipGraph_t dbg_g = nullptr; hipGraphExec_t dbg_ge = nullptr;      // cz_debug_decode_steps
+    int stream_prio = 0;                // HIP priority of this session's stream and of the decode lanes it makes (cz_debug_set "stream_priority")
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; int graph_B = 0, graph_max_nk = 0; unsigned long long graph_gen = 0;
     unsigned long long devbuf_gen = 0, graph_launch_ns = 0, graph_launch_cpu_ns = 0, graph_launch_idle_ns = 0; int probe_launch = 0;
     unsigned* fallback_dev = nullptr;   // rows the exact-parallel CDF kernel handed to the serial walk

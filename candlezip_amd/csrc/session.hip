@@ -1055,7 +1055,7 @@ static cz_status make_lane(cz_session* p, cz_session** out) {
     const bool rw = p->backend == CZ_BACKEND_RWKV7;
     if (rw && cz_rwkv7_make_lane(p, c) != CZ_OK) { cz_session_close(c); return CZ_ERR_HIP; }
     const size_t scratch = rw ? cz_cdf_par_scratch_bytes((int)cz_rwkv7_vocab(p), 1) : cz_cdf_par_scratch_bytes(c->llama.cfg.vocab, 0);
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->fallback_dev, 64) != hipSuccess ||
+    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, p->stream_prio) != hipSuccess || hipMalloc((void**)&c->fallback_dev, 64) != hipSuccess ||
         hipMemset(c->fallback_dev, 0, 64) != hipSuccess || (p->cdf_scratch && hipMalloc((void**)&c->cdf_scratch, scratch) != hipSuccess)) {
         cz_session_close(c); cz_set_error("cannot allocate a lane"); return CZ_ERR_HIP;
     }
@@ -1358,6 +1358,21 @@ static cz_status set_stream_xcd(cz_session* s, int xcd, int n_xcd) {
     return CZ_OK;
 }
 
+// replace this session's stream by one of another priority (HIP: lower number = higher priority; clamped to the device's range).
+// For a session that shares the device with latency-bound work of other sessions, e.g. a forked encoder beside decode lanes.
+static cz_status set_stream_priority(cz_session* s, int prio) {
+    if (s->graph_exec || s->run.active) { cz_set_error("stream_priority must be set before the first decode"); return CZ_ERR_STATE; }
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    if (prio > least) prio = least;
+    if (prio < greatest) prio = greatest;
+    hipStream_t ns = nullptr;
+    HIPCHK(hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, prio));
+    if (s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
+    s->stream = ns; s->stream_prio = prio;
+    return CZ_OK;
+}
+
 // test/bench knobs (not part of the drop-in surface): 0 = default kernels
 extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     if (!s || !key) return CZ_ERR_ARG;
@@ -1371,6 +1386,7 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "max_lanes")) s->max_lanes = (int)value;
     else if (!strcmp(key, "kv_ctx_cap")) { if (s->kvcache) { cz_set_error("kv_ctx_cap must be set before the first step / decode"); return CZ_ERR_STATE; } s->kv_ctx_cap = (int)value; }
     else if (!strcmp(key, "probe_launch")) s->probe_launch = (int)value;
+    else if (!strcmp(key, "stream_priority")) return set_stream_priority(s, (int)value);
     else if (!strcmp(key, "cu_mask_xcd")) return set_stream_xcd(s, (int)(value % 16), (int)(value / 16) + 1);   // value = first_xcd + 16 * (n_xcd - 1); -1: no mask
     else if (!strcmp(key, "step_sync")) s->step_sync = (int)value;
     else if (!strcmp(key, "wide_min_streams")) s->wide_min_streams = (int)value;
