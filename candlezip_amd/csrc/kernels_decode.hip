@@ -452,12 +452,14 @@ typedef __attribute__((address_space(1))) const float gfloat;     // K/V pointer
 template <int rep, int DA_WAVES>
 __global__ __launch_bounds__(DA_WAVES * 64, 4) void dec_attn_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
                                                               const cz_seq_desc* __restrict__ descs, int n_heads, int n_kv, int s_stride,
-                                                              size_t kv_off, const int* __restrict__ pos_dev, int out_kq) {
+                                                              size_t kv_off, const int* __restrict__ pos_dev, int out_kq, int kv_div) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     cz_seq_desc sd = descs[blockIdx.x];
     const int pos = pos_dev ? *pos_dev : sd.pos0;
     const int nk = pos + 1, nch = (nk + 63) >> 6;
-    const int kvh = blockIdx.y;
+    // kv_div == 1: block = (stream, kv head), its `rep` query heads share the K/V it streams.  kv_div > 1 (rep == 1; small grids, e.g. ONE
+    // stream): block = (stream, QUERY head), kv head = blockIdx.y / kv_div — three times the blocks re-read the same K/V, each a third of the work
+    const int kvh = blockIdx.y / kv_div, qh0 = kv_div > 1 ? (int)blockIdx.y : kvh * rep;
     gfloat* Kb = (gfloat*)(sd.k + kv_off + (sd.kt_stride ? (size_t)kvh * 64 * sd.kt_stride : (size_t)kvh * 64));
     gfloat* Vb = (gfloat*)(sd.v + kv_off + kvh * 64);
     // LDS sized by the launch for `rep` heads and the longest context the caller will reach (s_stride = 64 * chunks + 4): 26 KB at 1024
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(DA_WAVES * 64, 4) void dec_attn_kernel(const float*
     float* csum = red + DA_MAXW * DA_MAXREP;            // [rep][32]       chunk sums of e
     constexpr int DA_MAXC = 32 / DA_WAVES;              // chunks per wave: 32 chunks = 2048 keys per block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < rep * 64) qs[tid] = Q[(size_t)sd.row0 * ldq + (kvh * rep + (tid >> 6)) * 64 + (tid & 63)];
+    if (tid < rep * 64) qs[tid] = Q[(size_t)sd.row0 * ldq + (qh0 + (tid >> 6)) * 64 + (tid & 63)];
     __syncthreads();
     // ---- phase 1: scores of the wave's chunks (lane = key), kept in registers
     float sc[DA_MAXC][DA_MAXREP];
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(DA_WAVES * 64, 4) void dec_attn_kernel(const float*
         const int h = tid >> 6, dd = tid & 63;
         float t = part[(0 * rep + h) * 64 + dd];
         for (int c = 1; c < nch; ++c) t = t + part[(c * rep + h) * 64 + dd];
-        const int col = (kvh * rep + h) * 64 + dd;
+        const int col = (qh0 + h) * 64 + dd;
         O[(size_t)sd.row0 * ldo + (out_kq ? kq_index(col) : col)] = t;          // kq layout feeds dec_gemm_kernel's o-projection, natural layout the tiled GEMM
     }
 }
@@ -639,23 +641,29 @@ hipError_t cz_dec_attn_prepare(int max_nk) {
 int g_dec_attn_small_grid = 128;   // tuning knob (cz_debug_set "dec_attn_small_grid"): grids of at most this many blocks run 16 waves per block
 template <int W>
 static void da_launch(hipStream_t st, int rep, dim3 grid, size_t smem, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs,
-                      int n_heads, int n_kv, int ss, size_t kv_off, const int* pos_dev, int out_kq) {
+                      int n_heads, int n_kv, int ss, size_t kv_off, const int* pos_dev, int out_kq, int kv_div) {
     const dim3 block(W * 64);
     switch (rep) {
-        case 1: hipLaunchKernelGGL((dec_attn_kernel<1, W>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;
-        case 2: hipLaunchKernelGGL((dec_attn_kernel<2, W>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;
-        case 3: hipLaunchKernelGGL((dec_attn_kernel<3, W>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;
-        default: hipLaunchKernelGGL((dec_attn_kernel<4, W>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq); break;
+        case 1: hipLaunchKernelGGL((dec_attn_kernel<1, W>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, kv_div); break;
+        case 2: hipLaunchKernelGGL((dec_attn_kernel<2, W>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, kv_div); break;
+        case 3: hipLaunchKernelGGL((dec_attn_kernel<3, W>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, kv_div); break;
+        default: hipLaunchKernelGGL((dec_attn_kernel<4, W>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, kv_div); break;
     }
 }
+int g_dec_attn_split_heads = 1;     // tuning knob (cz_debug_set "dec_attn_split_heads"): 0 = never one block per query head
 hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nstreams, int max_nk,
                               int n_heads, int n_kv, size_t kv_off, const int* pos_dev, int out_kq) {
     if (nstreams <= 0) return hipSuccess;
     const int rep = n_heads / n_kv;
     if (rep < 1 || rep > DA_MAXREP || max_nk > 2048) return hipErrorInvalidValue;
+    const int ss = da_s_stride(max_nk);
+    if (g_dec_attn_split_heads && rep > 1 && nstreams * n_heads <= g_dec_attn_small_grid) {     // a handful of streams: one block per QUERY head (16 waves): -2 % step time at B = 1
+        da_launch<16>(st, 1, dim3(nstreams, n_heads), da_smem(max_nk, 1), Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, rep);
+        return hipGetLastError();
+    }
     const dim3 grid(nstreams, n_kv);
-    const size_t smem = da_smem(max_nk, rep); const int ss = da_s_stride(max_nk);
-    if (nstreams * n_kv <= g_dec_attn_small_grid) da_launch<16>(st, rep, grid, smem, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq);
-    else da_launch<8>(st, rep, grid, smem, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq);
+    const size_t smem = da_smem(max_nk, rep);
+    if (nstreams * n_kv <= g_dec_attn_small_grid) da_launch<16>(st, rep, grid, smem, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, 1);
+    else da_launch<8>(st, rep, grid, smem, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, 1);
     return hipGetLastError();
 }
