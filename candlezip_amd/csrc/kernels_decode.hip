@@ -625,7 +625,7 @@ static size_t da_smem(int max_nk, int rep) {
 }
 template <int rep, int W>
 static hipError_t da_prepare(int max_nk) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<rep, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem(max_nk, rep));
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<rep, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(da_smem(max_nk, rep) + 65536));   // (+ room for the dec_attn_lds_pad tuning knob)
 }
 hipError_t cz_dec_attn_prepare(int max_nk) {
     hipError_t e = da_prepare<1, 8>(max_nk);
@@ -650,6 +650,7 @@ static void da_launch(hipStream_t st, int rep, dim3 grid, size_t smem, const flo
         default: hipLaunchKernelGGL((dec_attn_kernel<4, W>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, kv_div); break;
     }
 }
+int g_dec_attn_lds_pad = 0;         // tuning knob (cz_debug_set "dec_attn_lds_pad"): extra dynamic LDS bytes per block of the whole-device grids (fewer blocks per CU)
 int g_dec_attn_split_heads = 1;     // tuning knob (cz_debug_set "dec_attn_split_heads"): 0 = never one block per query head
 hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nstreams, int max_nk,
                               int n_heads, int n_kv, size_t kv_off, const int* pos_dev, int out_kq) {
@@ -664,6 +665,6 @@ hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O,
     const dim3 grid(nstreams, n_kv);
     const size_t smem = da_smem(max_nk, rep);
     if (nstreams * n_kv <= g_dec_attn_small_grid) da_launch<16>(st, rep, grid, smem, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, 1);
-    else da_launch<8>(st, rep, grid, smem, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, 1);
+    else da_launch<8>(st, rep, grid, smem + (size_t)g_dec_attn_lds_pad, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, 1);
     return hipGetLastError();
 }

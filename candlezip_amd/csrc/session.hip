@@ -31,6 +31,7 @@ extern int g_dec_norm_mfma;
 extern int g_gemm_mid_rows;
 extern int g_mid_nw;
 extern int g_dec_attn_split_heads;
+extern int g_dec_attn_lds_pad;
 extern int g_dec_wide_rows;
 extern int g_dec_attn_small_grid;
 #define HIPCHK(expr)                                                                                   \
@@ -1395,6 +1396,7 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "gemm_mid_rows")) g_gemm_mid_rows = (int)value;
     else if (!strcmp(key, "mid_nw")) g_mid_nw = (int)value;
     else if (!strcmp(key, "dec_attn_split_heads")) g_dec_attn_split_heads = (int)value;
+    else if (!strcmp(key, "dec_attn_lds_pad")) g_dec_attn_lds_pad = (int)value;              // (before the first decode: the kernels' LDS limit is set once)
     else if (!strcmp(key, "dec_wide_rows")) g_dec_wide_rows = (int)value;
     else if (!strcmp(key, "dec_attn_small_grid")) g_dec_attn_small_grid = (int)value;
     else if (!strcmp(key, "dbg_skip")) s->dbg_skip = (int)value;          // tools/bench_decode_step.py: 1 = no attention, 2 = no GEMMs/norms (timing only; results are garbage)
