@@ -36,6 +36,7 @@ hipError_t cz_launch_gemm_mid_swiglu(hipStream_t st, const float* A, int lda, co
 hipError_t cz_launch_embed(hipStream_t st, const uint32_t* tok, const uint16_t* E, float* X, int M, int d);
 hipError_t cz_launch_rmsnorm(hipStream_t st, const float* X, int ldx, const uint16_t* w, float* Y, int ldy, int M, int d, float eps,
                              const int* row_index);
+hipError_t cz_launch_gather_rows(hipStream_t st, const float* X, int ldx, const int* rows, float* Y, int ldy, int M, int d);
 hipError_t cz_launch_rope(hipStream_t st, float* QKV, int ld, const cz_rope_desc* descs, int nseq, int max_rows, int n_heads,
                           int n_kv, const float* cs, const float* sn, size_t kv_off, const int* pos_dev);
 hipError_t cz_launch_swiglu(hipStream_t st, const float* GU, float* H, int M, int f);

@@ -62,10 +62,11 @@ struct cz_session {
     LlamaModel llama;
     Rwkv7Model* rwkv = nullptr;
     // packed-row work buffers
-    DevBuf tok, x, xn, qkv, gu, h, seqd, roped, rowidx, sym, clo, chi, xl, logits, payload, outids, decst;
+    DevBuf tok, x, xn, qkv, gu, h, seqd, roped, rowidx, sym, clo, chi, xl, logits, payload, outids, decst, seqd_q, xc, rc;   // seqd_q, xc, rc: llama_body's last layer on the wanted rows only
     size_t max_batch_rows = 98304, logit_batch_rows = 8192;
     int force_big_gemm = 0, serial_cdf = 0, decode_v1 = 0, no_graph = 0, fuse_norm = 0, step_sync = 0, dbg_skip = 0, wide_min_streams = 256, wide_mode = 3;
     hipGraph_t dbg_g = nullptr; hipGraphExec_t dbg_ge = nullptr;      // cz_debug_decode_steps
+    int no_last_prune = 0;              // test knob: 1 = the last layer's tail on every row (llama_body)
     int stream_prio = 0;                // HIP priority of this session's stream and of the decode lanes it makes (cz_debug_set "stream_priority")
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; int graph_B = 0, graph_max_nk = 0; unsigned long long graph_gen = 0;
     unsigned long long devbuf_gen = 0, graph_launch_ns = 0, graph_launch_cpu_ns = 0, graph_launch_idle_ns = 0; int probe_launch = 0;
@@ -75,7 +76,7 @@ struct cz_session {
     std::vector<cz_session*> lanes; bool is_lane = false; int max_lanes = 4;
     cz_session* fork_of = nullptr; std::vector<cz_session*> forks; bool orphan = false;   // cz_session_fork: a fork shares the parent's weights; closing the parent first orphans it (every call then fails)
     cz_session() {
-        DevBuf* all[] = {&tok, &x, &xn, &qkv, &gu, &h, &seqd, &roped, &rowidx, &sym, &clo, &chi, &xl, &logits, &payload, &outids, &decst};
+        DevBuf* all[] = {&tok, &x, &xn, &qkv, &gu, &h, &seqd, &roped, &rowidx, &sym, &clo, &chi, &xl, &logits, &payload, &outids, &decst, &seqd_q, &xc, &rc};
         for (DevBuf* b : all) b->gen = &devbuf_gen;
     }
     // lock-step streams

@@ -136,6 +136,23 @@ hipError_t cz_launch_rmsnorm(hipStream_t st, const float* X, int ldx, const uint
     return hipGetLastError();
 }
 
+// Y[i][:] = X[rows[i]][:]   (d % 4 == 0): the wanted rows of a packed batch, made contiguous for the last layer's tail
+__global__ void gather_rows_kernel(const float* __restrict__ X, int ldx, const int* __restrict__ rows, float* __restrict__ Y, int ldy, int M, int d) {
+    const int per_row = d / 4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (long)M * per_row; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / per_row), c = (int)(i % per_row);
+        *reinterpret_cast<f32x4*>(Y + (size_t)m * ldy + c * 4) = *reinterpret_cast<const f32x4*>(X + (size_t)rows[m] * ldx + c * 4);
+    }
+}
+hipError_t cz_launch_gather_rows(hipStream_t st, const float* X, int ldx, const int* rows, float* Y, int ldy, int M, int d) {
+    if (M <= 0) return hipSuccess;
+    if (d % 4) return hipErrorInvalidValue;
+    long n = (long)M * (d / 4);
+    int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, st, X, ldx, rows, Y, ldy, M, d);
+    return hipGetLastError();
+}
+
 // RoPE (candle_nn::rotary_emb::rope, non-interleaved halves; products rounded separately, no fma) applied in place to
 // the q heads of the fused QKV buffer; the k heads are rotated and written, together with v, to the per-sequence
 // destination (the KV cache for lock-step decode, or back in place for segment-parallel encode).

@@ -276,58 +276,90 @@ static cz_status build_llama(cz_session* s, const cz_model_desc* desc) {
 }
 
 // ------------------------------------------------------------------ the transformer body over M packed rows
-// tokens are in s->tok; on return s->x holds the residual stream [M][d].
+// The rows whose logits are wanted (encode: the rows that predict a coded symbol; re-prime: a stream's last row).  In the LAST layer every
+// row still needs its K and V (they are what the wanted rows attend to / what the cache keeps), but only the wanted rows need attention
+// output, o-projection and MLP: the layer's tail runs on them alone (encode: half the rows of a segment; re-prime: one row in 511).
+struct LastRows {
+    const cz_seq_desc* seqd_q;   // per sequence: the wanted QUERY rows (row0 = first wanted row, pos0 = its position; k/v as in seqd)
+    int max_rows_q;
+    const int* rows;             // device: packed index of every wanted row, in the order the head will ask for them
+    int n;
+};
+// tokens are in s->tok; on return s->x holds the residual stream [M][d] — or, with `last` and fewer wanted rows than rows, s->rc holds
+// the residual stream of the wanted rows [last->n][d] (returns that pointer in *compact).
 static cz_status llama_body(cz_session* s, int M, const cz_seq_desc* seqd, const cz_rope_desc* roped, int nseq, int max_rows,
-                            int max_nk, size_t kv_layer_stride, const int* pos_dev) {
+                            int max_nk, size_t kv_layer_stride, const int* pos_dev, const LastRows* last = nullptr, const float** compact = nullptr) {
     const LlamaModel& m = s->llama; const cz_llama_config& c = m.cfg;
     const int d = c.d_model, kvd = c.n_kv_heads * 64, f = c.d_ffn, nq = d + 2 * kvd;
+    if (compact) *compact = nullptr;
+    const bool prune = last && compact && last->n > 0 && last->n < M && !s->no_last_prune;
     CZCHK(s->x.ensure((size_t)M * d * 4)); CZCHK(s->xn.ensure((size_t)M * d * 4));
+    if (prune) { CZCHK(s->xc.ensure((size_t)last->n * d * 4)); CZCHK(s->rc.ensure((size_t)last->n * d * 4)); }
     const int big = s->force_big_gemm;
     const bool fused_gu = m.L[0].wgu_i && (M > 64 || big);        // SwiGLU in the gate|up GEMM epilogue: the 2f-wide intermediate is never allocated
-    CZCHK(s->qkv.ensure((size_t)M * nq * 4)); if (!fused_gu) CZCHK(s->gu.ensure((size_t)M * 2 * f * 4)); CZCHK(s->h.ensure((size_t)M * f * 4));
+    const bool fused_gu_q = prune && m.L[0].wgu_i && (last->n > 64 || big);
+    CZCHK(s->qkv.ensure((size_t)M * nq * 4));
+    if (!fused_gu) CZCHK(s->gu.ensure((size_t)M * 2 * f * 4));
+    else if (prune && !fused_gu_q) CZCHK(s->gu.ensure((size_t)last->n * 2 * f * 4));
+    CZCHK(s->h.ensure((size_t)M * f * 4));
     float *x = (float*)s->x.p, *xn = (float*)s->xn.p, *qkv = (float*)s->qkv.p, *gu = (float*)s->gu.p, *h = (float*)s->h.p;
     hipStream_t st = s->stream;
-    auto gemm = [&](const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R, int N, int K) -> hipError_t {
-        s->prof_begin(M <= 64 && !big ? PK_GEMM_SKINNY : (N % 128 ? PK_GEMM_N64 : PK_GEMM));      // 128x64 tiles when N % 128 != 0 (kernels_gemm.hip)
-        hipError_t e = cz_launch_gemm(st, A, lda, W, C, ldc, R, ldc, M, N, K, big);
-        s->prof_end(2.0 * M * (double)N * K, (double)N * K * 2 + (double)M * (N + K) * 4);
+    auto gemm = [&](int rows, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R, int N, int K) -> hipError_t {
+        s->prof_begin(rows <= 64 && !big ? PK_GEMM_SKINNY : (N % 128 ? PK_GEMM_N64 : PK_GEMM));      // 128x64 tiles when N % 128 != 0 (kernels_gemm.hip)
+        hipError_t e = cz_launch_gemm(st, A, lda, W, C, ldc, R, ldc, rows, N, K, big);
+        s->prof_end(2.0 * rows * (double)N * K, (double)N * K * 2 + (double)rows * (N + K) * 4);
         return e;
+    };
+    // the layer after attention on `rows` rows: xr = attn . Wo^T + xr; xr = MLP(norm(xr)) + xr   (attn is overwritten with the normed rows)
+    auto tail = [&](const LlamaModel::Layer& y, int rows, float* attn, float* xr, bool fused) -> cz_status {
+        HIPCHK(gemm(rows, attn, d, y.wo, xr, d, xr, d, d));                  // x = attn_out . Wo^T + x
+        s->prof_begin(PK_RMSNORM); HIPCHK(cz_launch_rmsnorm(st, xr, d, y.ln2, attn, d, rows, d, c.rms_eps, nullptr)); s->prof_end(0, (double)rows * d * 8);
+        if (fused) {                                        // silu(gate) * up in the GEMM epilogue
+            s->prof_begin(PK_GEMM);
+            HIPCHK(cz_launch_gemm_swiglu(st, attn, d, y.wgu_i, h, f, rows, f, d));
+            s->prof_end(4.0 * rows * (double)f * d, (double)f * d * 4 + (double)rows * (f + d) * 4);
+        } else {
+            HIPCHK(gemm(rows, attn, d, y.wgu, gu, 2 * f, nullptr, 2 * f, d));
+            s->prof_begin(PK_SWIGLU); HIPCHK(cz_launch_swiglu(st, gu, h, rows, f)); s->prof_end(0, (double)rows * f * 12);
+        }
+        HIPCHK(gemm(rows, h, f, y.wd, xr, d, xr, d, f));                     // x = mlp_out + x
+        return CZ_OK;
     };
     s->prof_begin(PK_EMBED);
     HIPCHK(cz_launch_embed(st, (const uint32_t*)s->tok.p, m.E, x, M, d));
     s->prof_end(0, (double)M * d * 6);
     for (int l = 0; l < c.n_layers; ++l) {
         const LlamaModel::Layer& y = m.L[l];
+        const bool pr = prune && l == c.n_layers - 1;
         s->prof_begin(PK_RMSNORM); HIPCHK(cz_launch_rmsnorm(st, x, d, y.ln1, xn, d, M, d, c.rms_eps, nullptr)); s->prof_end(0, (double)M * d * 8);
-        HIPCHK(gemm(xn, d, y.wqkv, qkv, nq, nullptr, nq, d));
+        HIPCHK(gemm(M, xn, d, y.wqkv, qkv, nq, nullptr, nq, d));
         s->prof_begin(PK_ROPE);
         HIPCHK(cz_launch_rope(st, qkv, nq, roped, nseq, max_rows, c.n_heads, c.n_kv_heads, m.rope_cos, m.rope_sin, (size_t)l * kv_layer_stride, pos_dev));
         s->prof_end(0, (double)M * nq * 8);
         s->prof_begin(PK_ATTN);
-        HIPCHK(cz_launch_attention(st, qkv, nq, xn, d, seqd, nseq, max_rows, max_nk, c.n_heads, c.n_kv_heads, (size_t)l * kv_layer_stride, pos_dev));
-        s->prof_end(4.0 * 64 * c.n_heads * (double)M * max_nk * 0.5, 0);
-        HIPCHK(gemm(xn, d, y.wo, x, d, x, d, d));                           // x = attn_out . Wo^T + x
-        s->prof_begin(PK_RMSNORM); HIPCHK(cz_launch_rmsnorm(st, x, d, y.ln2, xn, d, M, d, c.rms_eps, nullptr)); s->prof_end(0, (double)M * d * 8);
-        if (fused_gu) {                                     // silu(gate) * up in the GEMM epilogue
-            s->prof_begin(PK_GEMM);
-            HIPCHK(cz_launch_gemm_swiglu(st, xn, d, y.wgu_i, h, f, M, f, d));
-            s->prof_end(4.0 * M * (double)f * d, (double)f * d * 4 + (double)M * (f + d) * 4);
-        } else {
-            HIPCHK(gemm(xn, d, y.wgu, gu, 2 * f, nullptr, 2 * f, d));
-            s->prof_begin(PK_SWIGLU); HIPCHK(cz_launch_swiglu(st, gu, h, M, f)); s->prof_end(0, (double)M * f * 12);
-        }
-        HIPCHK(gemm(h, f, y.wd, x, d, x, d, f));                            // x = mlp_out + x
+        HIPCHK(cz_launch_attention(st, qkv, nq, xn, d, pr ? last->seqd_q : seqd, nseq, pr ? last->max_rows_q : max_rows, max_nk, c.n_heads, c.n_kv_heads,
+                                   (size_t)l * kv_layer_stride, pos_dev));
+        s->prof_end(4.0 * 64 * c.n_heads * (double)(pr ? last->n : M) * max_nk * 0.5, 0);
+        if (!pr) { CZCHK(tail(y, M, xn, x, fused_gu)); continue; }
+        float *xc = (float*)s->xc.p, *rc = (float*)s->rc.p;
+        s->prof_begin(PK_EMBED);
+        HIPCHK(cz_launch_gather_rows(st, xn, d, last->rows, xc, d, last->n, d));
+        HIPCHK(cz_launch_gather_rows(st, x, d, last->rows, rc, d, last->n, d));
+        s->prof_end(0, (double)last->n * d * 16);
+        CZCHK(tail(y, last->n, xc, rc, fused_gu_q));
+        *compact = rc;
     }
     return CZ_OK;
 }
 
 // final norm on selected rows + tied lm_head: logits[r][:] for r in [0, nrows) from residual rows row_index[r]
-static cz_status llama_head(cz_session* s, const int* row_index_dev, int nrows, float* logits) {
+// (xsrc != nullptr: the nrows rows are contiguous there — llama_body's compact residual — and row_index_dev is not used)
+static cz_status llama_head(cz_session* s, const int* row_index_dev, int nrows, float* logits, const float* xsrc = nullptr) {
     const LlamaModel& m = s->llama; const cz_llama_config& c = m.cfg;
     const int d = c.d_model;
     CZCHK(s->xl.ensure((size_t)nrows * d * 4));
     s->prof_begin(PK_RMSNORM);
-    HIPCHK(cz_launch_rmsnorm(s->stream, (const float*)s->x.p, d, m.lnf, (float*)s->xl.p, d, nrows, d, c.rms_eps, row_index_dev));
+    HIPCHK(cz_launch_rmsnorm(s->stream, xsrc ? xsrc : (const float*)s->x.p, d, m.lnf, (float*)s->xl.p, d, nrows, d, c.rms_eps, xsrc ? nullptr : row_index_dev));
     s->prof_end(0, (double)nrows * d * 8);
     const int big = s->force_big_gemm;
     s->prof_begin(nrows <= 64 && !big ? PK_GEMM_SKINNY : PK_GEMM);
@@ -509,21 +541,25 @@ static cz_status llama_step(cz_session* s, int B, int pos) {
 static cz_status llama_reprime(cz_session* s, int B, int hl) {
     if (hl <= 0 || hl > CZ_MAX_CTX || (s->ctx_cap && hl > (int)s->ctx_cap)) { cz_set_error("history length %d out of range", hl); return CZ_ERR_ARG; }
     const size_t kvd = (size_t)s->llama.cfg.n_kv_heads * 64;
-    std::vector<cz_seq_desc> sd(B); std::vector<cz_rope_desc> rd(B); std::vector<int> ri(B);
+    std::vector<cz_seq_desc> sd(B), sq(B); std::vector<cz_rope_desc> rd(B); std::vector<int> ri(B);
     for (int b = 0; b < B; ++b) {
         float* kb = s->kvcache + (size_t)b * s->kv_stream_stride;
         sd[b] = {b * hl, hl, 0, (int)kvd, kb, kb + s->ctx_cap * kvd, (int)s->ctx_cap, 0};
+        sq[b] = {b * hl + hl - 1, 1, hl - 1, (int)kvd, kb, kb + s->ctx_cap * kvd, (int)s->ctx_cap, 0};     // the last row: the only one whose logits are used
         rd[b] = {b * hl, hl, 0, (int)kvd, kb, kb + s->ctx_cap * kvd, (int)s->ctx_cap, 0};
         ri[b] = b * hl + hl - 1;
     }
     CZCHK(s->seqd.ensure(sd.size() * sizeof(cz_seq_desc))); CZCHK(s->roped.ensure(rd.size() * sizeof(cz_rope_desc)));
-    CZCHK(s->rowidx.ensure(ri.size() * 4));
+    CZCHK(s->rowidx.ensure(ri.size() * 4)); CZCHK(s->seqd_q.ensure(sq.size() * sizeof(cz_seq_desc)));
+    HIPCHK(hipMemcpyAsync(s->seqd_q.p, sq.data(), sq.size() * sizeof(cz_seq_desc), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->seqd.p, sd.data(), sd.size() * sizeof(cz_seq_desc), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->roped.p, rd.data(), rd.size() * sizeof(cz_rope_desc), hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipMemcpyAsync(s->rowidx.p, ri.data(), ri.size() * 4, hipMemcpyHostToDevice, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));       // host vectors go out of scope
-    CZCHK(llama_body(s, B * hl, (const cz_seq_desc*)s->seqd.p, (const cz_rope_desc*)s->roped.p, B, hl, hl, s->kv_layer_stride, nullptr));
-    return llama_head(s, (const int*)s->rowidx.p, B, s->step_logits);
+    const LastRows last{(const cz_seq_desc*)s->seqd_q.p, 1, (const int*)s->rowidx.p, B};
+    const float* xq = nullptr;
+    CZCHK(llama_body(s, B * hl, (const cz_seq_desc*)s->seqd.p, (const cz_rope_desc*)s->roped.p, B, hl, hl, s->kv_layer_stride, nullptr, &last, &xq));
+    return llama_head(s, (const int*)s->rowidx.p, B, s->step_logits, xq);
 }
 
 // size every packed-row buffer for M rows (and nlog logit rows) now, so that nothing moves later
@@ -534,6 +570,8 @@ static cz_status reserve_rows(cz_session* s, size_t M, size_t nlog) {
     if (!(s->llama.L[0].wgu_i && (M > 64 || s->force_big_gemm))) CZCHK(s->gu.ensure(M * 2 * f * 4));
     CZCHK(s->h.ensure(M * f * 4)); CZCHK(s->xl.ensure(nlog * d * 4));
     CZCHK(s->seqd.ensure(nlog * sizeof(cz_seq_desc))); CZCHK(s->roped.ensure(nlog * sizeof(cz_rope_desc))); CZCHK(s->rowidx.ensure(nlog * 4));
+    CZCHK(s->seqd_q.ensure(nlog * sizeof(cz_seq_desc))); CZCHK(s->xc.ensure(nlog * d * 4)); CZCHK(s->rc.ensure(nlog * d * 4));   // the last layer's tail on the wanted rows
+    if (nlog <= 64 && !s->force_big_gemm) CZCHK(s->gu.ensure(nlog * 2 * f * 4));
     return CZ_OK;
 }
 
@@ -631,7 +669,8 @@ static cz_status encode_llama(cz_session* s, size_t n_streams, const uint32_t* c
             M += T; max_rows = std::max(max_rows, (int)T); ++sj;
         }
         const int nseq = (int)(sj - si);
-        std::vector<uint32_t> tok(M), sym; std::vector<int> rowidx; std::vector<cz_seq_desc> sd(nseq); std::vector<cz_rope_desc> rd(nseq);
+        std::vector<uint32_t> tok(M), sym; std::vector<int> rowidx; std::vector<cz_seq_desc> sd(nseq), sq(nseq); std::vector<cz_rope_desc> rd(nseq);
+        int max_rows_q = 0;
         struct Dst { int stream; size_t i; }; std::vector<Dst> dst;
         CZCHK(s->qkv.ensure(M * (size_t)nq * 4));
         float* qkv = (float*)s->qkv.p;
@@ -644,6 +683,9 @@ static cz_status encode_llama(cz_session* s, size_t n_streams, const uint32_t* c
             float* kb = qkv + row * nq + d;                     // K/V stay in place inside the fused QKV rows
             sd[q] = {(int)row, (int)T, 0, nq, kb, kb + kvd, 0, 0};
             rd[q] = {(int)row, (int)T, 0, nq, kb, kb + kvd, 0, 0};
+            const int q0 = (int)(sg.start_i - sg.hist_start), nqr = (int)(sg.end_i - sg.start_i);     // the rows that predict a coded symbol
+            sq[q] = {(int)row + q0, nqr, q0, nq, kb, kb + kvd, 0, 0};
+            max_rows_q = std::max(max_rows_q, nqr);
             for (size_t i = sg.start_i; i < sg.end_i; ++i) {
                 rowidx.push_back((int)(row + (i - sg.hist_start)));
                 sym.push_back(src[i + 1]);
@@ -654,17 +696,21 @@ static cz_status encode_llama(cz_session* s, size_t n_streams, const uint32_t* c
         const size_t Lr = rowidx.size();
         CZCHK(s->tok.ensure(M * 4)); CZCHK(s->seqd.ensure(nseq * sizeof(cz_seq_desc))); CZCHK(s->roped.ensure(nseq * sizeof(cz_rope_desc)));
         CZCHK(s->rowidx.ensure(Lr * 4)); CZCHK(s->sym.ensure(Lr * 4)); CZCHK(s->clo.ensure(Lr * 4)); CZCHK(s->chi.ensure(Lr * 4));
+        CZCHK(s->seqd_q.ensure(nseq * sizeof(cz_seq_desc)));
         HIPCHK(hipMemcpyAsync(s->tok.p, tok.data(), M * 4, hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipMemcpyAsync(s->seqd.p, sd.data(), nseq * sizeof(cz_seq_desc), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->seqd_q.p, sq.data(), nseq * sizeof(cz_seq_desc), hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipMemcpyAsync(s->roped.p, rd.data(), nseq * sizeof(cz_rope_desc), hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipMemcpyAsync(s->rowidx.p, rowidx.data(), Lr * 4, hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipMemcpyAsync(s->sym.p, sym.data(), Lr * 4, hipMemcpyHostToDevice, s->stream));
-        CZCHK(llama_body(s, (int)M, (const cz_seq_desc*)s->seqd.p, (const cz_rope_desc*)s->roped.p, nseq, max_rows, max_rows, 0, nullptr));
+        const LastRows last{(const cz_seq_desc*)s->seqd_q.p, max_rows_q, (const int*)s->rowidx.p, (int)Lr};
+        const float* xq = nullptr;                               // != nullptr: the residual rows of rowidx, contiguous
+        CZCHK(llama_body(s, (int)M, (const cz_seq_desc*)s->seqd.p, (const cz_rope_desc*)s->roped.p, nseq, max_rows, max_rows, 0, nullptr, &last, &xq));
         const size_t LB = s->logit_batch_rows;
         CZCHK(s->logits.ensure(std::min(LB, Lr) * (size_t)c.vocab * 4));
         for (size_t r0 = 0; r0 < Lr; r0 += LB) {
             const int nr = (int)std::min(LB, Lr - r0);
-            CZCHK(llama_head(s, (const int*)s->rowidx.p + r0, nr, (float*)s->logits.p));
+            CZCHK(llama_head(s, (const int*)s->rowidx.p + r0, nr, (float*)s->logits.p, xq ? xq + r0 * (size_t)d : nullptr));
             s->prof_begin(PK_CDF);
             if (s->serial_cdf) HIPCHK(cz_launch_cdf_pairs_serial(s->stream, (const float*)s->logits.p, c.vocab, (const uint32_t*)s->sym.p + r0,
                                                                   (uint32_t*)s->clo.p + r0, (uint32_t*)s->chi.p + r0, nr, c.vocab, 0));
@@ -1066,7 +1112,7 @@ static cz_status make_lane(cz_session* p, cz_session** out) {
 }
 static void lane_inherit(const cz_session* s, cz_session* ls) {   // a lane runs with its parent's knobs
     ls->kv_ctx_cap = s->kv_ctx_cap; ls->serial_cdf = s->serial_cdf; ls->decode_v1 = s->decode_v1; ls->no_graph = s->no_graph; ls->force_big_gemm = s->force_big_gemm;
-    ls->max_batch_rows = s->max_batch_rows; ls->logit_batch_rows = s->logit_batch_rows; ls->step_sync = s->step_sync; ls->fuse_norm = s->fuse_norm; ls->wide_min_streams = s->wide_min_streams; ls->wide_mode = s->wide_mode; ls->dbg_skip = s->dbg_skip;
+    ls->max_batch_rows = s->max_batch_rows; ls->logit_batch_rows = s->logit_batch_rows; ls->step_sync = s->step_sync; ls->fuse_norm = s->fuse_norm; ls->wide_min_streams = s->wide_min_streams; ls->wide_mode = s->wide_mode; ls->dbg_skip = s->dbg_skip; ls->no_last_prune = s->no_last_prune;
 }
 // run `n_streams` streams as groups of <= max_streams on up to max_lanes lanes; group(ls, off, count) processes streams [off, off + count)
 template <class GroupFn>
@@ -1394,6 +1440,7 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "wide_min_streams")) s->wide_min_streams = (int)value;
     else if (!strcmp(key, "wide_mode")) s->wide_mode = (int)value;
     else if (!strcmp(key, "gemm_mid_rows")) g_gemm_mid_rows = (int)value;
+    else if (!strcmp(key, "no_last_prune")) s->no_last_prune = (int)value;
     else if (!strcmp(key, "mid_nw")) g_mid_nw = (int)value;
     else if (!strcmp(key, "dec_attn_split_heads")) g_dec_attn_split_heads = (int)value;
     else if (!strcmp(key, "dec_attn_lds_pad")) g_dec_attn_lds_pad = (int)value;              // (before the first decode: the kernels' LDS limit is set once)

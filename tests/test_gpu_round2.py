@@ -188,6 +188,7 @@ def test_wide_group_step_is_bitexact(cz, czo, shape, path):
     g.debug_set("dec_attn_split_heads", 0 if path == "hybrid" else 1)            # small grids: a block per kv head (0) / per query head (1, the default)
     if path == "tiled":
         g.debug_set("wide_min_streams", 1)                                # every group, even one stream, takes the tiled-GEMM step
+        g.debug_set("no_last_prune", 1)                                   # ... and the last layer runs its tail on every row (the other paths: wanted rows only)
     elif path.startswith("mid"):                                          # the K-group GEMM (kernels_gemm_mid.hip) for the four layer projections
         g.debug_set("wide_min_streams", 1); g.debug_set("wide_mode", 3)
         g.debug_set("mid_nw", {"mid": 4, "mid8": 8, "mid9": 0}[path])     # (process-wide knob: reset below)
