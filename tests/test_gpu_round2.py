@@ -275,3 +275,37 @@ def test_decode_with_payloads_fed_in_pieces(cz, backend):
         g.decode_begin_batch(first, lens); g.decode_feed_batch([b"x"] * 3)        # a decode begun with complete payloads takes no feed
     g.decode_end()
     g.close()
+
+
+def test_full_size_samples_round_trip_and_windowed_encode_agree(cz):
+    """BASELINE config 3's per-stream size (a 64 KiB enwik8 chunk = 17 408 tokens, 34 re-prime segments) at the SmolLM2-135M shape, where the
+    oracle would need hours: size-independent properties instead.  (1) the window-by-window range encode + incremental coder (the bench's
+    compress stage) gives byte for byte the payload of the one-shot encode; (2) groups of 3 + 2 streams on two lanes decode the input back,
+    34 re-primes each; (3) the payload of a stream does not depend on which other streams share its batch."""
+    import hashlib
+    T, W = 17408, 512
+    g = cz.Session("smollm", cz.smollm2_135m_config(), seed=0x5EED, embed_std=0.02, max_streams=3)
+    rng = np.random.default_rng(2024)
+    streams = [np.concatenate([[0], rng.integers(0, 49152, T)]).astype(np.uint32) for _ in range(5)]
+    pairs = g.encode_tokens_batch(streams, 512, 512)
+    payloads = [cz.ac_encode_pairs(lo, hi)[0] for lo, hi in pairs]
+    # (1) windows of 512 tokens, coder fed window by window
+    encs = [cz.AcEncoder() for _ in streams]
+    pieces = [b""] * len(streams)
+    for w in range(T // W):
+        part = g.encode_tokens_range_batch(streams, [(w * W, (w + 1) * W)] * len(streams), 512, 512)
+        for k, (lo, hi) in enumerate(part):
+            pieces[k] += encs[k].push(lo, hi)
+    for k in range(len(streams)):
+        pieces[k] += encs[k].finish()[0]
+        encs[k].close()
+    assert [hashlib.sha256(p).hexdigest() for p in pieces] == [hashlib.sha256(p).hexdigest() for p in payloads]
+    # (3) one stream alone
+    alone = g.encode_tokens_batch(streams[3:4], 512, 512)[0]
+    assert np.array_equal(alone[0], pairs[3][0]) and np.array_equal(alone[1], pairs[3][1])
+    # (2) decode: groups of 3 + 2 on two lanes
+    g.debug_set("max_lanes", 2)
+    outs2 = g.decode_tokens_batch(payloads, [T] * len(streams), 512, 512, 0)
+    for s_, o in zip(streams, outs2):
+        assert np.array_equal(s_, o)
+    g.close()
