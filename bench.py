@@ -81,6 +81,23 @@ def pmc_traffic(prefix, tokens=1536):
     return (round(tot) if tot else None), "; ".join(notes)
 
 
+def rocprof_avg_us(prefix, tokens):
+    """average kernel duration of a kernel function from the committed rocprofv3 --kernel-trace --stats summary of the pass this script
+    measures its rooflines on (profiles/r*_pass<tokens>_*kernel_stats.csv, tools/prof_summary.py; newest round first).  The HIP-event figure
+    next to it brackets launch + kernel + the gap to the next event record, so it reads a few us longer per launch."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pass{tokens}_*kernel_stats.csv")), reverse=True)
+    for f in files:
+        calls = 0; tot = 0.0
+        for r in csv.DictReader(open(f)):
+            if r["kernel"].startswith(prefix):
+                calls += int(r["calls"]); tot += float(r["total_ms"])
+        if calls:
+            return round(1e3 * tot / calls, 3), os.path.basename(f)
+    return None, None
+
+
 class Generation:
     """one 64 KiB sample per stream: ids, one incremental arithmetic encoder per stream, the payload bytes not yet handed to the decoder"""
 
@@ -112,7 +129,7 @@ class SelfTestPipeline:
         self.nwin = -(-n_tokens // window)
         self.gens = {}
         self.cg = self.cw = self.dg = self.dw = 0                # compress / decompress cursors: (generation, window)
-        self.te = self.td = 0.0; self.tok = 0; self.bytes = 0; self.verified = 0
+        self.te = self.td = 0.0; self.tok = 0; self.bytes = 0; self.verified = 0; self.windows_verified = 0
 
     def _window(self, w):
         return w * self.W, min((w + 1) * self.W, self.T)
@@ -171,12 +188,22 @@ class SelfTestPipeline:
             import threading
             self._feed()
             box = {}
-            th = threading.Thread(target=lambda: box.__setitem__("te", self._compress_next()))
+
+            def work():
+                try:
+                    box["te"] = self._compress_next()
+                except BaseException as ex:                      # re-raised on the main thread below: never a KeyError that hides it
+                    box["err"] = ex
+            th = threading.Thread(target=work)
             th.start()
             t = time.perf_counter()
-            self.sess.decode_advance(e - b)
-            self.td += time.perf_counter() - t
-            th.join()
+            try:
+                self.sess.decode_advance(e - b)
+            finally:
+                self.td += time.perf_counter() - t
+                th.join()
+            if "err" in box:
+                raise box["err"]
             self.te += box["te"]
         else:
             self.te += self._compress_next()
@@ -189,7 +216,7 @@ class SelfTestPipeline:
         if self.dw == self.nwin:                                 # generation complete: verify, move on to the next one
             t = time.perf_counter()
             self._check(self.T)
-            self.verified += 1
+            self.verified += 1; self.windows_verified += self.nwin
             self.bytes += self._gen(self.dg).bytes
             self.sess.decode_end()
             del self.gens[self.dg]
@@ -200,17 +227,47 @@ class SelfTestPipeline:
     def finish(self):
         """verify what has been decoded of the generation in flight, release the slot"""
         self._check(self._window(self.dw)[0] if self.dw else 0)
+        self.windows_verified += self.dw
         self.sess.decode_end()
 
 
-def self_test_step(cz, sess, streams, context, reprime):
-    """one-shot compress + decompress of every stream (the eager per-family profiling pass)"""
+def profile_pass(cz, sess, streams, context, reprime, skip):
+    """the eager per-family pass on STEADY-STATE contexts: the first `skip` tokens of every stream — the ramp-up 1 -> 512 keys, which a
+    17 408-token stream sees during 1/34 of its life — run with the timers off; the timed part is whole re-prime periods of the sawtooth the
+    timed region lives in (511 -> 1023 keys at the defaults, mean 767).  Encode: the range [skip, n) (whole segments when skip is a multiple of
+    the re-prime interval); decode: the sliced loop, timers switched on after the first slice.  Round trip verified.  Returns the merged
+    family table."""
+    n = [s.size - 1 for s in streams]
+    sess.profile_enable(False)
     pairs = sess.encode_tokens_batch(streams, context, reprime)
     payloads = [cz.ac_encode_pairs(lo, hi)[0] for lo, hi in pairs]
-    outs = sess.decode_tokens_batch(payloads, [s.size - 1 for s in streams], context, reprime, 0)
+    sess.profile_enable(True)
+    part = sess.encode_tokens_range_batch(streams, [(min(skip, k), k) for k in n], context, reprime)
+    prof = sess.profile_read()
+    sess.profile_enable(False)
+    for (lo, hi), (plo, phi), k in zip(pairs, part, n):
+        if not (np.array_equal(lo[min(skip, k):], plo) and np.array_equal(hi[min(skip, k):], phi)):
+            raise RuntimeError("range encode differs from the one-shot encode")
+    sess.debug_set("no_graph", 1)                                # eager launches: every family can be bracketed by events
+    sess.decode_begin_batch(payloads, n, context, reprime, 0)
+    if skip:
+        sess.decode_advance(skip)
+    sess.profile_enable(True)
+    sess.decode_advance(max(n))
+    dec = sess.profile_read()
+    sess.profile_enable(False)
+    outs = sess.decode_fetch_batch()
+    sess.decode_end()
+    sess.debug_set("no_graph", 0)
     for s, o in zip(streams, outs):
         if not np.array_equal(s, o):
             raise RuntimeError("self-test round trip mismatch")
+    for k, v in dec.items():
+        if k in prof:
+            prof[k] = {f: prof[k][f] + v[f] for f in v}
+        else:
+            prof[k] = v
+    return prof
 
 
 def cpu_baseline(sample_tokens, context, reprime):
@@ -236,6 +293,35 @@ def cpu_baseline(sample_tokens, context, reprime):
             "compress_tokens_per_s": round(sample_tokens / (t1 - t0), 2), "decompress_tokens_per_s": round(sample_tokens / (t2 - t1), 2)}
 
 
+def spawn_ranks(n, argv=None, script=None):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh child ranks, one per GPU, BEFORE anything in this process has
+    touched the GPU (children are new processes; nothing that initialised HIP is ever exec'd).  Rank 0's stdout — the ONE JSON line — is
+    this process's stdout; the exit code is the worst child's.  A rank that dies takes the others down (they would wait at a barrier)."""
+    import socket
+    import subprocess
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC only on this pool (RCCL across processes)
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv), env=env,
+                                      stdout=(None if r == 0 else subprocess.DEVNULL)))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = rc or (code if code > 0 else 128 - code)
+                for q in live:                                   # exact PIDs of our own children
+                    q.terminate()
+        time.sleep(0.2)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,7 +337,8 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="no HIP-event timing inside the timed region (for rocprofv3 --pmc)")
     ap.add_argument("--step-sync", action="store_true", help="with --no-graph: synchronise after every decode step, so that launches never queue up (rocprofv3 --pmc, DESIGN.md §9)")
     ap.add_argument("--kv-ctx-cap", type=int, default=0, help="tuning: positions per stream in the KV cache (0 = library default 2048)")
-    ap.add_argument("--profile-tokens", type=int, default=1536, help="tokens/stream of the untimed eager per-family profiling pass (0 = skip)")
+    ap.add_argument("--profile-tokens", type=int, default=2048, help="tokens/stream of the untimed eager per-family profiling pass (0 = skip); its first --profile-skip tokens run with the timers off")
+    ap.add_argument("--profile-skip", type=int, default=-1, help="tokens/stream at the start of the profiling pass that are not timed (the ramp-up to the steady-state sawtooth); -1 = one re-prime interval")
     ap.add_argument("--context", type=int, default=512)
     ap.add_argument("--reprime-interval", type=int, default=512)
     ap.add_argument("--cpu-sample", type=int, default=640, help="tokens of the CPU-baseline sample (0 = skip)")
@@ -260,11 +347,16 @@ def main():
     ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE", help="library tuning knob (cz_debug_set)")
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check only)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # no launcher: be one (before any GPU call in this process)
+        sys.exit(spawn_ranks(args.gpus))
 
-    import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # One rank needs no torch at all: the product is libcandlezip_hip.so on the system ROCm runtime it links (ldd: /opt/rocm/lib/libamdhip64.so.7).
+    # Importing torch first would put torch's BUNDLED libamdhip64 under this library instead — and under rocprofv3 that is a ROCm-7.0 HIP runtime
+    # over the profiler's ROCm-7.2 HSA runtime in one process (the --pmc crash).  torch is plumbing for the N > 1 rendezvous only.
     if world > 1:
+        import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("CZ_BENCH_DIST_BACKEND", "nccl")       # "gloo": rehearsal of the N > 1 path on a one-GPU box
@@ -305,10 +397,10 @@ def main():
         shutil.copy("/proc/self/maps", os.environ["CZ_DUMP_MAPS"])
 
     def barrier():
-        torch.cuda.synchronize()
+        sess.synchronize()                                       # hipDeviceSynchronize: every lane and fork of this rank
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            sess.synchronize()
 
     sess.profile_enable(False)
     pipe.fill()                                                           # untimed: the compress stage two windows ahead, the decode opened
@@ -340,8 +432,10 @@ def main():
         sess.profile_enable(True)
         rng = np.random.default_rng(99)
         short = [np.concatenate([[0], rng.integers(0, cfg.vocab, args.profile_tokens)]).astype(np.uint32) for _ in range(min(per_lane, len(mine)))]
-        self_test_step(cz, sess, short, args.context, args.reprime_interval)
-        prof_all = sess.profile_read()
+        skip = args.profile_skip if args.profile_skip >= 0 else min(args.reprime_interval, args.profile_tokens // 2)
+        prof_all = profile_pass(cz, sess, short, args.context, args.reprime_interval, skip)
+        if args.no_graph:
+            sess.debug_set("no_graph", 1)
         note("eager per-family pass done")
     sess.profile_enable(False)
     if dist is not None:
@@ -372,9 +466,16 @@ def main():
                 r = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5)}
             traffic, tnote = pmc_traffic(prefix, args.profile_tokens)
             n = max(st["launches"], 1)
+            rp_us, rp_src = rocprof_avg_us(prefix, args.profile_tokens)
             r.update({"traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": tnote, "kernel": fn + " (all instantiations)", "families": fams,
                       "algorithmic_per_launch": round((st["flops"] if bound == "mfma" else st["bytes"]) / n), "algorithmic_unit": "flop" if bound == "mfma" else "bytes",
-                      "launches": st["launches"], "avg_launch_us": round(1e3 * ms / n, 3), "total_ms": round(ms, 2), "measured_in": where})
+                      "launches": st["launches"], "avg_launch_us": round(1e3 * ms / n, 3),
+                      "avg_launch_us_note": "HIP events around each launch on the library's stream: kernel + launch gap; `achieved` is computed from this figure",
+                      "avg_kernel_us_rocprof": rp_us, "avg_kernel_us_rocprof_source": rp_src, "total_ms": round(ms, 2), "measured_in": where})
+            if rp_us:
+                alg = (st["flops"] if bound == "mfma" else st["bytes"]) / n
+                r["achieved_rocprof"] = round(alg / (rp_us * 1e-6) / (1e12 if bound == "mfma" else 1e9), 3)
+                r["frac_rocprof"] = round(r["achieved_rocprof"] / (FP32_MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS), 4)
             return r
 
         if per_lane >= 256:      # wide lock-step groups: the layer projections run on gemm_mid_kernel, lm_head and the norms on the big-M kernels
@@ -382,8 +483,9 @@ def main():
             FUNCTIONS["gemm_mid_kernel"] = (["dec_gemm_plain", "dec_gemm_qkv_rope", "dec_gemm_swiglu"], "mfma", "gemm_mid_kernel<")
             FUNCTIONS["gemm_bf16w_kernel (decode lm_head)"] = (["dec_gemm_lm_head"], "mfma", "gemm_bf16w_kernel<128, 128, 2, 2, 0>")
             FUNCTIONS["rmsnorm_kernel"] = (["rmsnorm", "dec_rmsnorm"], "hbm", "rmsnorm_kernel")
-        where = (f"eager per-family pass inside bench.py ({min(per_lane, len(mine))} streams x {args.profile_tokens} tokens: the workload's own context sawtooth, up to "
-                 "1023 keys; one decode lane); the timed region replays hipGraphs on concurrent lanes")
+        where = (f"eager per-family pass inside bench.py ({min(per_lane, len(mine))} streams x {args.profile_tokens} tokens, the first "
+                 f"{args.profile_skip if args.profile_skip >= 0 else min(args.reprime_interval, args.profile_tokens // 2)} untimed: whole periods of the steady-state context "
+                 "sawtooth the timed region lives in; one decode lane); the timed region replays hipGraphs on concurrent lanes")
         by_fn = {fn: merged(prof_all, FUNCTIONS[fn][0]) for fn in FUNCTIONS}
         dominant = max(by_fn, key=lambda f: by_fn[f]["total_ms"]) if prof_all else "dec_attn_kernel"
         roof = roof_of(dominant, by_fn[dominant], where)
@@ -401,7 +503,8 @@ def main():
                        "window_tokens": args.window, "compress_beside_decompress": bool(args.overlap), "parallelism": f"files x{world} (LPT work list, no data-path collective)"},
             "bits_per_byte": None,
             "bits_per_token_synthetic": round(8.0 * pipe.bytes / max(pipe.verified * len(mine) * args.sample_tokens, 1), 3) if pipe.verified else None,
-            "generations_verified": pipe.verified,
+            "generations_verified": pipe.verified, "windows_verified": pipe.windows_verified,
+            "ranks_seen": (dist.get_world_size() if dist is not None else 1), "dist_backend": (dist.get_backend() if dist is not None else None),
             "compress_tokens_per_s_rank0": round(tok / te, 1) if te else None,
             "decompress_tokens_per_s_rank0": round(tok / td, 1) if td else None,
             "halves_note": ("the two halves of a step ran at the same time and shared the device: each rate is lower than alone (--overlap 0 times them alone)"

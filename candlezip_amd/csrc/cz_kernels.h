@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include "cz_numerics.h"
 
+#define CZ_KERNEL_MAX_CTX 8192     // longest context the attention kernels take (max_position_embeddings of SmolLM2-135M)
+
 // one attention "sequence": rows [row0, row0+nrows) of the activation batch sit at positions pos0.. and attend to
 // keys/values k[j*kv_stride + kvh*64 + d], j in [0, pos0 + local_row]
 struct cz_seq_desc {
@@ -23,6 +25,10 @@ struct cz_rope_desc {
     int pad_;
 };
 
+// dynamic-LDS limits of the GEMM kernels: call once per device (session open) before the first launch
+hipError_t cz_gemm_prepare();
+hipError_t cz_gemm_mid_prepare();
+hipError_t cz_dec_gemm_prepare();
 hipError_t cz_launch_gu_interleave(hipStream_t st, const uint16_t* W, uint16_t* Wi, int f, int K);
 hipError_t cz_launch_gemm_swiglu(hipStream_t st, const float* A, int lda, const uint16_t* Wi, float* H, int ldh, int M, int f, int K);
 hipError_t cz_launch_gemm(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R, int ldr,

@@ -6,7 +6,8 @@
 #include "../../include/candlezip.h"
 #include "cz_kernels.h"
 
-#define CZ_MAX_CTX 2048      // longest attention window the kernels keep in LDS (reference sawtooth peaks at 1535)
+#define CZ_DEF_CTX 2048      // positions per stream the KV cache starts with (the reference's default sawtooth peaks at 1023, config 5's at 1535);
+                             // a run that needs more (a re-prime interval > 1536) gets a cache sized for it, up to cz_ctx_limit()
 
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
@@ -75,13 +76,13 @@ struct cz_session {
     // decode lanes: independent lock-step groups replayed concurrently on their own HIP streams (share the weights)
     std::vector<cz_session*> lanes; bool is_lane = false; int max_lanes = 4;
     cz_session* fork_of = nullptr; std::vector<cz_session*> forks; bool orphan = false;   // cz_session_fork: a fork shares the parent's weights; closing the parent first orphans it (every call then fails)
-    cz_session() {
-        DevBuf* all[] = {&tok, &x, &xn, &qkv, &gu, &h, &seqd, &roped, &rowidx, &sym, &clo, &chi, &xl, &logits, &payload, &outids, &decst, &seqd_q, &xc, &rc};
-        for (DevBuf* b : all) b->gen = &devbuf_gen;
+    std::vector<DevBuf*> all_bufs() {   // ONE list for the constructor and cz_session_close (a buffer missing from either leaks or dangles)
+        return {&tok, &x, &xn, &qkv, &gu, &h, &seqd, &roped, &rowidx, &sym, &clo, &chi, &xl, &logits, &payload, &outids, &decst, &seqd_q, &xc, &rc};
     }
+    cz_session() { for (DevBuf* b : all_bufs()) b->gen = &devbuf_gen; }
     // lock-step streams
     int max_streams = 64;
-    size_t ctx_cap = 0, kv_layer_stride = 0, kv_stream_stride = 0; int kv_ctx_cap = 0;   // kv_ctx_cap: requested positions per stream (0 = CZ_MAX_CTX)
+    size_t ctx_cap = 0, kv_layer_stride = 0, kv_stream_stride = 0; int kv_ctx_cap = 0;   // kv_ctx_cap: positions per stream the cache starts with (0 = CZ_DEF_CTX)
     float* kvcache = nullptr;          // [stream][layer][K|V][ctx_cap][n_kv*64]
     int* pos_dev = nullptr;
     cz_seq_desc* step_seqd = nullptr; cz_rope_desc* step_roped = nullptr; int* step_rows = nullptr;

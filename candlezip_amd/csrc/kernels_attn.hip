@@ -431,6 +431,216 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
             if (qr < rows_here) O[(size_t)(row_base + qr) * ldo + (kvh * REP + rt) * 64 + wave * 16 + li] = tot[rt][r];
         }
 }
+// ------------------------------------------------------------------------------------------------------------
+// attention_v3_kernel<REP>: the same arithmetic for ANY context length (re-prime intervals past 1536 tokens: a segment of up to
+// max_position_embeddings rows).  v2 keeps the score tiles of all chunks in registers (<= 24 chunks at REP 3), v1 keeps them in LDS
+// (<= 2048 keys); here nothing is kept: QK^T is evaluated three times, chunk by chunk — pass 1 the row maxima, pass 2 e = exp(s - max)
+// and the canonical row sums (chunk sums on the MFMA, added left to right as they come), pass 3 p = e / sum and P.V.  Every pass
+// recomputes bit-identical scores, so the result equals v2's wherever both run (tests/test_gpu_kernels.py).  LDS: one K tile, one V tile,
+// one e/p tile, the Q operand (65 KB at REP 3).
+template <int REP>
+__global__ __launch_bounds__(256, 2) void attention_v3_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
+                                                              const cz_seq_desc* __restrict__ descs, size_t kv_off, const int* __restrict__ pos_dev) {
+    __shared__ __attribute__((aligned(16))) float Ks_[64 * V2_KS];
+    __shared__ __attribute__((aligned(16))) float Vs_[64 * V2_VS];
+    __shared__ __attribute__((aligned(16))) float Et_[REP * 16 * V2_KS];
+    __shared__ __attribute__((aligned(16))) float Qs[REP * 64 * V2_QS];
+    __shared__ float wred[4][REP * 16];
+    __shared__ float rsum[REP * 16];
+    cz_seq_desc sd = descs[blockIdx.z];
+    if (pos_dev) sd.pos0 = *pos_dev;
+    sd.k += kv_off; sd.v += kv_off;
+    const int tile = blockIdx.x, kvh = blockIdx.y;
+    if (tile * 16 >= sd.nrows) return;
+    const int rows_here = sd.nrows - tile * 16 < 16 ? sd.nrows - tile * 16 : 16;
+    const int nk_blk = sd.pos0 + tile * 16 + rows_here;
+    const int nch = (nk_blk + 63) / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int row_base = sd.row0 + tile * 16;
+    if (wave == 0) {                                   // Q operand, lane-contiguous (as v2's QLDS form); clamped loads, select afterwards
+        const bool valid = li < rows_here;
+#pragma unroll
+        for (int rt = 0; rt < REP; ++rt) {
+            const float* qp = Q + (size_t)(row_base + (valid ? li : 0)) * ldq + (kvh * REP + rt) * 64 + lg;
+            float raw[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) raw[t] = qp[4 * t];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) Qs[(rt * 64 + lane) * V2_QS + t] = valid ? raw[t] : 0.0f;
+        }
+    }
+    auto load_kv = [&](const float* base, int kt_stride, int c, f32x4* out) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int key = (tid >> 4) + 16 * p, q4 = tid & 15;
+            const int j = c * 64 + key;
+            const int jj = j < nk_blk ? j : nk_blk - 1;               // clamp (never a conditional load), zero afterwards
+            f32x4 v;
+            if (kt_stride) {
+                const float* kp = base + (size_t)(kvh * 64 + q4 * 4) * kt_stride + jj;
+                v = f32x4{kp[0], kp[kt_stride], kp[2 * (size_t)kt_stride], kp[3 * (size_t)kt_stride]};
+            } else v = *reinterpret_cast<const f32x4*>(base + (size_t)jj * sd.kv_stride + kvh * 64 + q4 * 4);
+            if (j >= nk_blk) v = f32x4{0, 0, 0, 0};
+            out[p] = v;
+        }
+    };
+    // scores of chunk c (K tile already in Ks_, behind a barrier): sc[rt][r] = row 4 lg + r, key c*64 + wave*16 + li
+    auto scores = [&](int c, f32x4* sc) {
+        const float* kbp = Ks_ + (wave * 16 + li) * V2_KS + lg;
+        const int key = c * 64 + wave * 16 + li;
+#pragma unroll
+        for (int rt = 0; rt < REP; ++rt) {
+            f32x4 acc = f32x4{0, 0, 0, 0};
+            const f32x4* qp4 = reinterpret_cast<const f32x4*>(Qs + (rt * 64 + lane) * V2_QS);
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const f32x4 q = qp4[t4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q[t], kbp[4 * (4 * t4 + t)], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qr = 4 * lg + r;
+                float v = acc[r] * 0.125f;
+                if (qr >= rows_here || key > sd.pos0 + tile * 16 + qr) v = -INFINITY;
+                sc[rt][r] = v;
+            }
+        }
+    };
+    auto store_k = [&](const f32x4* pre) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(Ks_ + ((tid >> 4) + 16 * p) * V2_KS + (tid & 15) * 4) = pre[p];
+    };
+    f32x4 prek[4], prev[4];
+    // ---- pass 1: row maxima (exact in any order)
+    float gmax[REP][4];
+#pragma unroll
+    for (int rt = 0; rt < REP; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gmax[rt][r] = -INFINITY;
+    load_kv(sd.k, sd.kt_stride, 0, prek);
+    for (int c = 0; c < nch; ++c) {
+        store_k(prek);
+        __syncthreads();
+        if (c + 1 < nch) load_kv(sd.k, sd.kt_stride, c + 1, prek);
+        f32x4 sc[REP];
+        scores(c, sc);
+#pragma unroll
+        for (int rt = 0; rt < REP; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gmax[rt][r] = sc[rt][r] > gmax[rt][r] ? sc[rt][r] : gmax[rt][r];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int rt = 0; rt < REP; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m = gmax[rt][r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { const float y = __shfl_xor(m, o); m = y > m ? y : m; }
+            if (li == 0) wred[wave][rt * 16 + 4 * lg + r] = m;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < REP; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = rt * 16 + 4 * lg + r;
+            float m = wred[0][s];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) m = wred[w][s] > m ? wred[w][s] : m;
+            gmax[rt][r] = m;
+        }
+    // ---- pass 2: e = exp(s - max); canonical row sums: the chunk sum on the MFMA (B = 1: fma(e_k, 1, acc) == acc + e_k), chunks left to right
+    f32x4 run = f32x4{0, 0, 0, 0};                      // wave < REP: the running row sums of head `wave` (rows 4 lg + r)
+    load_kv(sd.k, sd.kt_stride, 0, prek);
+    for (int c = 0; c < nch; ++c) {
+        store_k(prek);
+        __syncthreads();
+        if (c + 1 < nch) load_kv(sd.k, sd.kt_stride, c + 1, prek);
+        f32x4 sc[REP];
+        scores(c, sc);
+#pragma unroll
+        for (int rt = 0; rt < REP; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qr = 4 * lg + r;
+                Et_[(rt * 16 + qr) * V2_KS + wave * 16 + li] = qr < rows_here ? cz_expf(sc[rt][r] - gmax[rt][r]) : 0.0f;
+            }
+        __syncthreads();
+        if (wave < REP) {
+            const float* pa = Et_ + (wave * 16 + li) * V2_KS + lg;
+            f32x4 sacc = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 16; ++t) sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * t], 1.0f, sacc, 0, 0, 0);
+            if (c == 0) run = sacc;
+            else
+#pragma unroll
+                for (int r = 0; r < 4; ++r) run[r] = run[r] + sacc[r];
+        }
+    }
+    if (wave < REP && li == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rsum[wave * 16 + 4 * lg + r] = run[r];
+    }
+    __syncthreads();
+    float rs[REP][4];
+#pragma unroll
+    for (int rt = 0; rt < REP; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rs[rt][r] = rsum[rt * 16 + 4 * lg + r];
+    // ---- pass 3: p = e / sum ; out = P.V (wave w -> output columns 16w.., chunks in order)
+    f32x4 tot[REP];
+#pragma unroll
+    for (int rt = 0; rt < REP; ++rt) tot[rt] = f32x4{0, 0, 0, 0};
+    load_kv(sd.k, sd.kt_stride, 0, prek);
+    load_kv(sd.v, 0, 0, prev);
+    for (int c = 0; c < nch; ++c) {
+        store_k(prek);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(Vs_ + ((tid >> 4) + 16 * p) * V2_VS + (tid & 15) * 4) = prev[p];
+        __syncthreads();
+        if (c + 1 < nch) { load_kv(sd.k, sd.kt_stride, c + 1, prek); load_kv(sd.v, 0, c + 1, prev); }
+        f32x4 sc[REP];
+        scores(c, sc);
+#pragma unroll
+        for (int rt = 0; rt < REP; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qr = 4 * lg + r;
+                Et_[(rt * 16 + qr) * V2_KS + wave * 16 + li] = qr < rows_here ? cz_expf(sc[rt][r] - gmax[rt][r]) / rs[rt][r] : 0.0f;
+            }
+        __syncthreads();
+        const float* vbp = Vs_ + lg * V2_VS + wave * 16 + li;
+#pragma unroll
+        for (int rt = 0; rt < REP; ++rt) {
+            const float* pa = Et_ + (rt * 16 + li) * V2_KS + lg;
+            f32x4 acc = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * t], vbp[4 * t * V2_VS], acc, 0, 0, 0);
+            if (c == 0) tot[rt] = acc;
+            else
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tot[rt][r] = tot[rt][r] + acc[r];
+        }
+        __syncthreads();                                   // Ks_ / Vs_ / Et_ are free for the next chunk
+    }
+#pragma unroll
+    for (int rt = 0; rt < REP; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qr = 4 * lg + r;
+            if (qr < rows_here) O[(size_t)(row_base + qr) * ldo + (kvh * REP + rt) * 64 + wave * 16 + li] = tot[rt][r];
+        }
+}
+template <int REP>
+static hipError_t launch_v3(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nseq, int max_rows,
+                            int n_kv, size_t kv_off, const int* pos_dev) {
+    const dim3 grid((max_rows + 15) / 16, n_kv, nseq), block(256);
+    hipLaunchKernelGGL((attention_v3_kernel<REP>), grid, block, 0, st, Q, ldq, O, ldo, descs, kv_off, pos_dev);
+    return hipGetLastError();
+}
 template <int REP>
 static hipError_t launch_v2(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nseq, int max_rows, int max_nk,
                             int n_kv, size_t kv_off, const int* pos_dev) {
@@ -443,10 +653,11 @@ static hipError_t launch_v2(hipStream_t st, const float* Q, int ldq, float* O, i
     return hipGetLastError();
 }
 
-int g_attn_v1 = 0;     // test knob: 1 = the LDS-resident v1 kernel
+int g_attn_v1 = 0;     // test knob: 1 = the LDS-resident v1 kernel, 2 = the three-pass v3 kernel wherever it can run (rep <= 4)
 static int s_stride_for(int max_nk) { return ((max_nk + 63) / 64) * 64 + 4; }
 size_t cz_attention_smem_bytes(int max_nk) { return (size_t)(16 * s_stride_for(max_nk) + 64 * VS + 16 * 32 + 16) * sizeof(float); }
 hipError_t cz_attention_prepare(int max_nk) {
+    if (max_nk > 2048) max_nk = 2048;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)cz_attention_smem_bytes(max_nk));
 }
@@ -458,7 +669,7 @@ hipError_t cz_launch_attention(hipStream_t st, const float* Q, int ldq, float* O
     // v2 keeps NI*REP score tiles in registers: beyond these shapes the compiler spills them, so v1 (LDS-resident) takes over
     const int ni_ = (max_nk + 63) / 64;
     const bool v2_fits = (rep <= 2 && ni_ <= 32) || (rep == 3 && ni_ <= 24) || (rep == 4 && ni_ <= 16);
-    if (!g_attn_v1 && v2_fits && max_rows > 1) {
+    if (g_attn_v1 == 0 && v2_fits && max_rows > 1) {
         switch (rep) {
             case 1: return launch_v2<1>(st, Q, ldq, O, ldo, descs, nseq, max_rows, max_nk, n_kv, kv_off, pos_dev);
             case 2: return launch_v2<2>(st, Q, ldq, O, ldo, descs, nseq, max_rows, max_nk, n_kv, kv_off, pos_dev);
@@ -466,6 +677,15 @@ hipError_t cz_launch_attention(hipStream_t st, const float* Q, int ldq, float* O
             default: return launch_v2<4>(st, Q, ldq, O, ldo, descs, nseq, max_rows, max_nk, n_kv, kv_off, pos_dev);
         }
     }
+    if (g_attn_v1 != 1 && rep <= 4 && (max_rows > 1 || max_nk > 2048 || g_attn_v1 == 2)) {      // contexts past what v2's registers (and v1's LDS) hold: the three-pass kernel
+        switch (rep) {
+            case 1: return launch_v3<1>(st, Q, ldq, O, ldo, descs, nseq, max_rows, n_kv, kv_off, pos_dev);
+            case 2: return launch_v3<2>(st, Q, ldq, O, ldo, descs, nseq, max_rows, n_kv, kv_off, pos_dev);
+            case 3: return launch_v3<3>(st, Q, ldq, O, ldo, descs, nseq, max_rows, n_kv, kv_off, pos_dev);
+            default: return launch_v3<4>(st, Q, ldq, O, ldo, descs, nseq, max_rows, n_kv, kv_off, pos_dev);
+        }
+    }
+    if (max_nk > 2048) return hipErrorInvalidValue;         // v1 keeps a [16][nk] score tile in LDS
     const int RT = 16 / rep;
     const int ss = s_stride_for(max_nk);
     dim3 grid((max_rows + RT - 1) / RT, n_kv, nseq);

@@ -327,17 +327,34 @@ static hipError_t dec_gemm_launch_mt(hipStream_t st, const dec_gemm_args& a, int
     const int NW = dec_nw(a.K);
     const int G = MT < 2 ? MT : 2;
     const size_t smem = (size_t)NW * G * NP * 2 * 16 * 17 * sizeof(float);
-    auto kern = dec_gemm_kernel<EPI, NORM, MT, NP>;
-    if (smem > 48 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 2 * NP * 2 * 16 * 17 * (int)sizeof(float));
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
-    }
+    auto kern = dec_gemm_kernel<EPI, NORM, MT, NP>;          // (NP = 2 blocks pass 48 KB of LDS: cz_dec_gemm_prepare, once per device at session open)
     hipLaunchKernelGGL(kern, dim3(gx / NP, (a.M + MT * 16 - 1) / (MT * 16)), dim3(64 * NW), smem, st, a);
     return hipGetLastError();
+}
+template <int EPI, int NORM, int MT, int NP>
+static hipError_t dec_gemm_prepare_one() {     // up to 12 waves x min(MT, 2) row tiles x NP pairs x 2 tiles of [16][17] partials: past 48 KB from MT = 2 on
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm_kernel<EPI, NORM, MT, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 2 * NP * 2 * 16 * 17 * (int)sizeof(float));
+}
+template <int EPI>
+static hipError_t dec_gemm_prepare_epi() {
+    hipError_t e = dec_gemm_prepare_one<EPI, 0, 2, 1>();
+    if (e == hipSuccess) e = dec_gemm_prepare_one<EPI, 0, 4, 1>();
+    if (e == hipSuccess) e = dec_gemm_prepare_one<EPI, 0, 8, 1>();
+    if (e == hipSuccess) e = dec_gemm_prepare_one<EPI, 1, 2, 1>();
+    if (e == hipSuccess) e = dec_gemm_prepare_one<EPI, 1, 4, 1>();
+    if (e == hipSuccess) e = dec_gemm_prepare_one<EPI, 1, 8, 1>();
+    if (e == hipSuccess) e = dec_gemm_prepare_one<EPI, 2, 2, 1>();
+    if (e == hipSuccess) e = dec_gemm_prepare_one<EPI, 0, 2, 2>();
+    if (e == hipSuccess) e = dec_gemm_prepare_one<EPI, 1, 2, 2>();
+    if (e == hipSuccess) e = dec_gemm_prepare_one<EPI, 2, 2, 2>();
+    return e;
+}
+hipError_t cz_dec_gemm_prepare() {
+    hipError_t e = dec_gemm_prepare_epi<EPI_PLAIN>();
+    if (e == hipSuccess) e = dec_gemm_prepare_epi<EPI_ROPE>();
+    if (e == hipSuccess) e = dec_gemm_prepare_epi<EPI_SWIGLU>();
+    if (e == hipSuccess) e = dec_gemm_prepare_epi<EPI_RELUSQ>();
+    return e;
 }
 int g_dec_grid_target = 384;     // tuning knob (cz_debug_set "dec_grid_target")
 int g_dec_mt_max = 8;            // tuning knob (cz_debug_set "dec_mt_max"): most 16-row tiles per block
@@ -449,8 +466,11 @@ typedef __attribute__((address_space(1))) const float gfloat;     // K/V pointer
                                                                   // compiler they are global (global_load, not flat_load)
 // rep = query heads per kv head (compile-time so that the per-head code carries no branches); DA_WAVES = 8 waves per block for whole-device
 // grids, 16 where the grid is small (a single stream has n_kv blocks in all: twice the waves halve the chunks each wave walks serially)
-template <int rep, int DA_WAVES>
-__global__ __launch_bounds__(DA_WAVES * 64, 4) void dec_attn_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
+// DA_MAXC = key chunks per wave: DA_WAVES * DA_MAXC chunks = the longest context of the instantiation (32 chunks = 2048 keys for the two
+// everyday shapes; 16 waves x 8 = 128 chunks = 8192 keys = max_position_embeddings of SmolLM2 for the long variant, whose chunk partials
+// of P.V are handed over in rounds of DA_WAVES chunks so that its LDS stays under 160 KB: scores 98 KB at rep 3).
+template <int rep, int DA_WAVES, int DA_MAXC>
+__global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : 4)) void dec_attn_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
                                                               const cz_seq_desc* __restrict__ descs, int n_heads, int n_kv, int s_stride,
                                                               size_t kv_off, const int* __restrict__ pos_dev, int out_kq, int kv_div) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -467,10 +487,11 @@ __global__ __launch_bounds__(DA_WAVES * 64, 4) void dec_attn_kernel(const float*
     const int nch_max = (s_stride - 4) >> 6;
     float* qs = smem;                                   // [rep][64]
     float* S = qs + rep * 64;                           // [rep][s_stride]  e, then p
-    float* part = S + rep * s_stride;                   // [nch_max][rep][64]   chunk partials of P.V
-    float* red = part + nch_max * rep * 64;             // [DA_WAVES][DA_MAXREP] local maxima
-    float* csum = red + DA_MAXW * DA_MAXREP;            // [rep][32]       chunk sums of e
-    constexpr int DA_MAXC = 32 / DA_WAVES;              // chunks per wave: 32 chunks = 2048 keys per block
+    constexpr bool LONG = DA_MAXC > 4;                   // (rounds of DA_WAVES chunk partials instead of all nch_max at once)
+    constexpr int CS = DA_WAVES * DA_MAXC;               // chunks per block = stride of the chunk sums
+    float* part = S + rep * s_stride;                   // [nch_max][rep][64]   chunk partials of P.V ([DA_WAVES][rep][64] per round when LONG)
+    float* red = part + (LONG ? DA_WAVES : nch_max) * rep * 64;             // [DA_WAVES][DA_MAXREP] local maxima
+    float* csum = red + DA_MAXW * DA_MAXREP;            // [rep][CS]       chunk sums of e
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < rep * 64) qs[tid] = Q[(size_t)sd.row0 * ldq + (qh0 + (tid >> 6)) * 64 + (tid & 63)];
     __syncthreads();
@@ -555,7 +576,7 @@ __global__ __launch_bounds__(DA_WAVES * 64, 4) void dec_attn_kernel(const float*
             float acc = 0.0f;
 #pragma unroll 16
             for (int k = 0; k < 64; ++k) acc = acc + p[k];
-            csum[lane * 32 + c] = acc;
+            csum[lane * CS + c] = acc;
         }
     }
     __syncthreads();
@@ -564,7 +585,7 @@ __global__ __launch_bounds__(DA_WAVES * 64, 4) void dec_attn_kernel(const float*
 #pragma unroll
     for (int h = 0; h < DA_MAXREP; ++h) {
         float t = 0.0f;
-        if (h < rep) { t = csum[h * 32]; for (int c = 1; c < nch; ++c) t = t + csum[h * 32 + c]; }
+        if (h < rep) { t = csum[h * CS]; for (int c = 1; c < nch; ++c) t = t + csum[h * CS + c]; }
         tot[h] = t;
     }
 #pragma unroll
@@ -577,9 +598,11 @@ __global__ __launch_bounds__(DA_WAVES * 64, 4) void dec_attn_kernel(const float*
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0xc07f);
+    float osum = 0.0f;                                   // LONG: thread (h, d)'s running total over the chunks, in chunk order
 #pragma unroll
     for (int i = 0; i < DA_MAXC; ++i) {
         const int c = wave + DA_WAVES * i;
+        if (LONG && DA_WAVES * i >= nch) break;          // (block-uniform: the rounds below hold barriers)
         if (c < nch) {
             float acc[DA_MAXREP] = {0.0f, 0.0f, 0.0f, 0.0f};
             const int jend = nk - c * 64 < 64 ? nk - c * 64 : 64;
@@ -606,28 +629,52 @@ __global__ __launch_bounds__(DA_WAVES * 64, 4) void dec_attn_kernel(const float*
                 }
             }
 #pragma unroll
-            for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) part[(c * rep + h) * 64 + lane] = acc[h];
+            for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) part[((LONG ? wave : c) * rep + h) * 64 + lane] = acc[h];
+        }
+        if (LONG) {     // round i = chunks [DA_WAVES i, DA_WAVES (i + 1)): a contiguous range, so adding the rounds one after the other keeps the chunk order
+            __syncthreads();
+            if (tid < rep * 64) {
+                const int h = tid >> 6, dd = tid & 63;
+                const int lim = nch - DA_WAVES * i < DA_WAVES ? nch - DA_WAVES * i : DA_WAVES;
+                for (int w = 0; w < lim; ++w) { const float pw = part[(w * rep + h) * 64 + dd]; osum = (i == 0 && w == 0) ? pw : osum + pw; }
+            }
+            __syncthreads();
         }
     }
-    __syncthreads();
+    if (!LONG) __syncthreads();
     if (tid < rep * 64) {
         const int h = tid >> 6, dd = tid & 63;
-        float t = part[(0 * rep + h) * 64 + dd];
-        for (int c = 1; c < nch; ++c) t = t + part[(c * rep + h) * 64 + dd];
+        float t = osum;
+        if (!LONG) {
+            t = part[(0 * rep + h) * 64 + dd];
+            for (int c = 1; c < nch; ++c) t = t + part[(c * rep + h) * 64 + dd];
+        }
         const int col = (qh0 + h) * 64 + dd;
         O[(size_t)sd.row0 * ldo + (out_kq ? kq_index(col) : col)] = t;          // kq layout feeds dec_gemm_kernel's o-projection, natural layout the tiled GEMM
     }
 }
+#define DA_LONG_W 16
+#define DA_LONG_C 8                                   // 16 waves x 8 chunks x 64 keys = 8192 positions
 static int da_s_stride(int max_nk) { return ((max_nk + 63) / 64) * 64 + 4; }
 static size_t da_smem(int max_nk, int rep) {
     const int nch = (max_nk + 63) / 64;
     return (size_t)(rep * 64 + rep * da_s_stride(max_nk) + nch * rep * 64 + DA_MAXW * DA_MAXREP + rep * 32) * sizeof(float);
 }
+static size_t da_smem_long(int max_nk, int rep) {
+    return (size_t)(rep * 64 + rep * da_s_stride(max_nk) + DA_LONG_W * rep * 64 + DA_MAXW * DA_MAXREP + rep * DA_LONG_W * DA_LONG_C) * sizeof(float);
+}
 template <int rep, int W>
 static hipError_t da_prepare(int max_nk) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<rep, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(da_smem(max_nk, rep) + 65536));   // (+ room for the dec_attn_lds_pad tuning knob)
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<rep, W, 32 / W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(da_smem(max_nk, rep) + 65536));   // (+ room for the dec_attn_lds_pad tuning knob)
 }
+template <int rep>
+static hipError_t da_prepare_long() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_kernel<rep, DA_LONG_W, DA_LONG_C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)da_smem_long(CZ_KERNEL_MAX_CTX, rep));
+}
+// per device, at session open (the attribute belongs to the current device's copy of the kernel): everyday variants up to `max_nk` <= 2048 keys,
+// the long variant up to CZ_KERNEL_MAX_CTX
 hipError_t cz_dec_attn_prepare(int max_nk) {
+    if (max_nk > 2048) max_nk = 2048;
     hipError_t e = da_prepare<1, 8>(max_nk);
     if (e == hipSuccess) e = da_prepare<2, 8>(max_nk);
     if (e == hipSuccess) e = da_prepare<3, 8>(max_nk);
@@ -636,18 +683,22 @@ hipError_t cz_dec_attn_prepare(int max_nk) {
     if (e == hipSuccess) e = da_prepare<2, 16>(max_nk);
     if (e == hipSuccess) e = da_prepare<3, 16>(max_nk);
     if (e == hipSuccess) e = da_prepare<4, 16>(max_nk);
+    if (e == hipSuccess) e = da_prepare_long<1>();
+    if (e == hipSuccess) e = da_prepare_long<2>();
+    if (e == hipSuccess) e = da_prepare_long<3>();
+    if (e == hipSuccess) e = da_prepare_long<4>();
     return e;
 }
 int g_dec_attn_small_grid = 128;   // tuning knob (cz_debug_set "dec_attn_small_grid"): grids of at most this many blocks run 16 waves per block
-template <int W>
+template <int W, int MC>
 static void da_launch(hipStream_t st, int rep, dim3 grid, size_t smem, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs,
                       int n_heads, int n_kv, int ss, size_t kv_off, const int* pos_dev, int out_kq, int kv_div) {
     const dim3 block(W * 64);
     switch (rep) {
-        case 1: hipLaunchKernelGGL((dec_attn_kernel<1, W>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, kv_div); break;
-        case 2: hipLaunchKernelGGL((dec_attn_kernel<2, W>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, kv_div); break;
-        case 3: hipLaunchKernelGGL((dec_attn_kernel<3, W>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, kv_div); break;
-        default: hipLaunchKernelGGL((dec_attn_kernel<4, W>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, kv_div); break;
+        case 1: hipLaunchKernelGGL((dec_attn_kernel<1, W, MC>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, kv_div); break;
+        case 2: hipLaunchKernelGGL((dec_attn_kernel<2, W, MC>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, kv_div); break;
+        case 3: hipLaunchKernelGGL((dec_attn_kernel<3, W, MC>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, kv_div); break;
+        default: hipLaunchKernelGGL((dec_attn_kernel<4, W, MC>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, kv_div); break;
     }
 }
 int g_dec_attn_lds_pad = 0;         // tuning knob (cz_debug_set "dec_attn_lds_pad"): extra dynamic LDS bytes per block of the whole-device grids (fewer blocks per CU)
@@ -656,15 +707,19 @@ hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O,
                               int n_heads, int n_kv, size_t kv_off, const int* pos_dev, int out_kq) {
     if (nstreams <= 0) return hipSuccess;
     const int rep = n_heads / n_kv;
-    if (rep < 1 || rep > DA_MAXREP || max_nk > 2048) return hipErrorInvalidValue;
+    if (rep < 1 || rep > DA_MAXREP || max_nk > CZ_KERNEL_MAX_CTX) return hipErrorInvalidValue;
     const int ss = da_s_stride(max_nk);
+    if (max_nk > 2048) {            // contexts past 2048 keys (a re-prime interval > 1536): the 16-wave variant whose waves walk 8 chunks each
+        da_launch<DA_LONG_W, DA_LONG_C>(st, rep, dim3(nstreams, n_kv), da_smem_long(max_nk, rep), Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, 1);
+        return hipGetLastError();
+    }
     if (g_dec_attn_split_heads && rep > 1 && nstreams * n_heads <= g_dec_attn_small_grid) {     // a handful of streams: one block per QUERY head (16 waves): -2 % step time at B = 1
-        da_launch<16>(st, 1, dim3(nstreams, n_heads), da_smem(max_nk, 1), Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, rep);
+        da_launch<16, 2>(st, 1, dim3(nstreams, n_heads), da_smem(max_nk, 1), Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, rep);
         return hipGetLastError();
     }
     const dim3 grid(nstreams, n_kv);
     const size_t smem = da_smem(max_nk, rep);
-    if (nstreams * n_kv <= g_dec_attn_small_grid) da_launch<16>(st, rep, grid, smem, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, 1);
-    else da_launch<8>(st, rep, grid, smem + (size_t)g_dec_attn_lds_pad, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, 1);
+    if (nstreams * n_kv <= g_dec_attn_small_grid) da_launch<16, 2>(st, rep, grid, smem, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, 1);
+    else da_launch<8, 4>(st, rep, grid, smem + (size_t)g_dec_attn_lds_pad, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, 1);
     return hipGetLastError();
 }

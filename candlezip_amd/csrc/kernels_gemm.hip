@@ -235,17 +235,27 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const float* __restric
 template <int BM, int BN, int WM, int WN, int EPI = 0>
 static hipError_t launch_big(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R,
                              int ldr, int M, int N, int K) {
-    static bool attr_set = false;
     const size_t smem = (size_t)(BM + BN) * LDK * sizeof(float);
-    auto kern = gemm_bf16w_kernel<BM, BN, WM, WN, EPI>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    auto kern = gemm_bf16w_kernel<BM, BN, WM, WN, EPI>;        // (its LDS limit is raised by cz_gemm_prepare, once per device at session open)
     const int nbx = N / BN, nby = (M + BM - 1) / BM, nblocks = nbx * nby;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, st, A, lda, W, C, ldc, R, ldr, M, N, K, nbx, nblocks);
     return hipGetLastError();
+}
+
+template <int BM, int BN, int EPI>
+static hipError_t big_prepare() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16w_kernel<BM, BN, 2, 2, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)((size_t)(BM + BN) * LDK * sizeof(float)));
+}
+// per device, at session open: dynamic-LDS limits of every instantiation the launchers below use (a lazily set process-wide flag would
+// leave a second device's kernels at the 48 KB default and race between the host threads of the decode lanes)
+hipError_t cz_gemm_prepare() {
+    hipError_t e = big_prepare<64, 128, 1>();
+    if (e == hipSuccess) e = big_prepare<128, 128, 1>();
+    if (e == hipSuccess) e = big_prepare<64, 64, 0>();
+    if (e == hipSuccess) e = big_prepare<128, 128, 0>();
+    if (e == hipSuccess) e = big_prepare<128, 64, 0>();
+    return e;
 }
 
 // Wi[(c / 32) * 64 + (c % 32)] = gate row c, Wi[(c / 32) * 64 + 32 + (c % 32)] = up row c     (W = [gate rows (f) | up rows (f)], each K wide)

@@ -248,17 +248,30 @@ __global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : 1) void gemm_mi
 template <int TN, int EPI, int NW, bool PF>
 static hipError_t launch_mid_nw(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* C, int ldc, const float* R, int ldr, int M, int N, int K,
                                 mid_rope_args ra) {
-    static bool attr_set = false;
     const size_t smem = (size_t)(NW * 32 * MID_LDK + 4) * sizeof(float);
-    auto kern = gemm_mid_kernel<TN, EPI, NW, PF>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    auto kern = gemm_mid_kernel<TN, EPI, NW, PF>;            // (LDS limit: cz_gemm_mid_prepare, once per device at session open)
     const int nbx = N / (32 * TN), nby = (M + 31) / 32, nblocks = nbx * nby;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NW * 64), smem, st, A, lda, Wk, C, ldc, R, ldr, M, N, K, nbx, nblocks, ra);
     return hipGetLastError();
+}
+template <int TN, int EPI, int NW, bool PF>
+static hipError_t mid_prepare_one() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_mid_kernel<TN, EPI, NW, PF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)((size_t)(NW * 32 * MID_LDK + 4) * sizeof(float)));
+}
+template <int TN, int EPI>
+static hipError_t mid_prepare_epi() {
+    hipError_t e = mid_prepare_one<TN, EPI, 4, true>();
+    if (e == hipSuccess) e = mid_prepare_one<TN, EPI, 8, true>();
+    if (e == hipSuccess) e = mid_prepare_one<TN, EPI, 9, false>();
+    if (e == hipSuccess) e = mid_prepare_one<TN, EPI, TN == 1 ? 12 : 8, true>();
+    return e;
+}
+hipError_t cz_gemm_mid_prepare() {
+    hipError_t e = mid_prepare_epi<1, 0>();
+    if (e == hipSuccess) e = mid_prepare_epi<2, 1>();
+    if (e == hipSuccess) e = mid_prepare_epi<1, 2>();
+    return e;
 }
 // K groups per block.  Measured on 512-row groups (profiles/r02_microbench/call24_*): four groups with operand prefetch beat a wave per
 // 64-chunk (nine waves, one round for K = 576: +8 % step time) and summing on the round's last wave instead of its first (the wave with

@@ -162,6 +162,9 @@ fail:
 }
 
 // rows at positions pos0.. attend to K/V rows [0, pos0+m]; Q/O [M][nh*64], K/V [pos0+M][nkv*64]
+extern int g_attn_v1;
+// test hook: which prefill-attention kernel cz_launch_attention picks (0 = by shape, 1 = v1, 2 = v3)
+extern "C" void cz_debug_attn_variant(int v) { g_attn_v1 = v; }
 extern "C" cz_status cz_debug_attention(const float* Q, const float* K, const float* V, float* O, int M, int pos0, int nh, int nkv) {
     DevMem m;
     const int nk = pos0 + M;

@@ -369,34 +369,79 @@ static cz_status llama_head(cz_session* s, const int* row_index_dev, int nrows, 
 }
 
 // ------------------------------------------------------------------ lock-step streams (KV cache resident in HBM)
-static cz_status ensure_streams(cz_session* s, int B) {
+// longest context a stream of this model may reach: the reference fails past max_position_embeddings (candle's RoPE tables end there,
+// src/models.rs:94 -> Llama::forward); the attention kernels take CZ_KERNEL_MAX_CTX positions
+static inline size_t cz_ctx_limit(const cz_session* s) { return (size_t)std::min(s->llama.cfg.max_pos, CZ_KERNEL_MAX_CTX); }
+// old cache [stream][layer][K^T [kvd][oc] | V [oc][kvd]] -> the same layout with nc >= oc positions per stream
+__global__ void kv_regrow_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n_sl /* streams x layers */, int kvd, size_t oc, size_t nc) {
+    const size_t per = 2 * oc * kvd;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_sl * per; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t sl = i / per, r = i % per;
+        size_t o;
+        if (r < oc * kvd) { const size_t d = r / oc, j = r % oc; o = d * nc + j; }     // K transposed: row d keeps its keys 0..oc-1
+        else o = nc * kvd + (r - oc * kvd);                                             // V rows are contiguous
+        dst[sl * 2 * nc * kvd + o] = src[i];
+    }
+}
+// the lock-step streams' resident state; need_ctx = positions per stream the caller is about to use (0: whatever is there).  A cache that
+// is too short is replaced by a longer one (preserve: with its contents, for a single-stream session that steps past it); captured step
+// graphs hold the old strides, so devbuf_gen moves with it.
+static cz_status ensure_streams(cz_session* s, int B, size_t need_ctx = 0, bool preserve = false) {
     const cz_llama_config& c = s->llama.cfg;
     const size_t kvd = (size_t)c.n_kv_heads * 64;
     if (B > s->max_streams) { cz_set_error("%d streams exceed max_streams = %d", B, s->max_streams); return CZ_ERR_ARG; }
-    if (!s->kvcache) {
-        s->ctx_cap = s->kv_ctx_cap ? (size_t)s->kv_ctx_cap : (size_t)CZ_MAX_CTX;
-        s->kv_layer_stride = 2 * s->ctx_cap * kvd;
-        s->kv_stream_stride = (size_t)c.n_layers * s->kv_layer_stride;
-        HIPCHK(hipMalloc((void**)&s->kvcache, (size_t)s->max_streams * s->kv_stream_stride * 4));
-        HIPCHK(hipMalloc((void**)&s->pos_dev, 64));
+    if (need_ctx > cz_ctx_limit(s)) {
+        cz_set_error("a stream would reach %zu positions: beyond max_position_embeddings = %d (the reference fails there too) / the kernels' %d", need_ctx, c.max_pos, CZ_KERNEL_MAX_CTX);
+        return CZ_ERR_STATE;
+    }
+    const bool fresh = !s->kvcache;
+    if (fresh || need_ctx > s->ctx_cap) {
+        size_t cap = s->kv_ctx_cap ? (size_t)s->kv_ctx_cap : (size_t)CZ_DEF_CTX;
+        if (!fresh && preserve) cap = std::max(cap, 2 * s->ctx_cap);              // a stepping stream grows geometrically
+        cap = std::max(cap, (need_ctx + 255) / 256 * 256);
+        cap = std::min(cap, (cz_ctx_limit(s) + 255) / 256 * 256);
+        const size_t layer_stride = 2 * cap * kvd, stream_stride = (size_t)c.n_layers * layer_stride;
+        float* nk = nullptr;
+        if (hipMalloc((void**)&nk, (size_t)s->max_streams * stream_stride * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            cz_set_error("cannot allocate the KV cache: %d streams x %zu positions = %.1f GB (lower max_streams, or the re-prime interval)", s->max_streams, cap,
+                         (double)s->max_streams * stream_stride * 4 / 1e9);
+            return CZ_ERR_HIP;
+        }
+        if (!fresh) {
+            HIPCHK(hipStreamSynchronize(s->stream));
+            if (preserve) {
+                hipLaunchKernelGGL(kv_regrow_kernel, dim3(2048), dim3(256), 0, s->stream, s->kvcache, nk, (size_t)s->max_streams * c.n_layers, (int)kvd, s->ctx_cap, cap);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(s->stream));
+            }
+            HIPCHK(hipFree(s->kvcache));
+            ++s->devbuf_gen;                                                     // captured graphs hold kv offsets of the old capacity
+        }
+        s->kvcache = nk; s->ctx_cap = cap; s->kv_layer_stride = layer_stride; s->kv_stream_stride = stream_stride;
         std::vector<cz_seq_desc> sd(s->max_streams); std::vector<cz_rope_desc> rd(s->max_streams);
         for (int b = 0; b < s->max_streams; ++b) {
             float* kb = s->kvcache + (size_t)b * s->kv_stream_stride;
             sd[b] = {b, 1, 0, (int)kvd, kb, kb + s->ctx_cap * kvd, (int)s->ctx_cap, 0};     // K transposed [kvd][ctx_cap], V rows [ctx_cap][kvd]
             rd[b] = {b, 1, 0, (int)kvd, kb, kb + s->ctx_cap * kvd, (int)s->ctx_cap, 0};
         }
-        HIPCHK(hipMalloc((void**)&s->step_seqd, sd.size() * sizeof(cz_seq_desc)));
-        HIPCHK(hipMalloc((void**)&s->step_roped, rd.size() * sizeof(cz_rope_desc)));
+        if (fresh) {
+            HIPCHK(hipMalloc((void**)&s->pos_dev, 64));
+            HIPCHK(hipMalloc((void**)&s->step_seqd, sd.size() * sizeof(cz_seq_desc)));
+            HIPCHK(hipMalloc((void**)&s->step_roped, rd.size() * sizeof(cz_rope_desc)));
+        }
         // (never the legacy stream here: another decode lane may be capturing its step graph at this moment)
         HIPCHK(hipMemcpyAsync(s->step_seqd, sd.data(), sd.size() * sizeof(cz_seq_desc), hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipMemcpyAsync(s->step_roped, rd.data(), rd.size() * sizeof(cz_rope_desc), hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
-        std::vector<int> ri(s->max_streams); for (int b = 0; b < s->max_streams; ++b) ri[b] = b;
-        HIPCHK(hipMalloc((void**)&s->step_rows, ri.size() * 4));
-        HIPCHK(hipMemcpyAsync(s->step_rows, ri.data(), ri.size() * 4, hipMemcpyHostToDevice, s->stream));
-        HIPCHK(hipStreamSynchronize(s->stream));
-        HIPCHK(hipMalloc((void**)&s->step_logits, (size_t)s->max_streams * c.vocab * 4));
-        HIPCHK(hipMalloc((void**)&s->step_sym, (size_t)s->max_streams * 4));
+        if (fresh) {
+            std::vector<int> ri(s->max_streams); for (int b = 0; b < s->max_streams; ++b) ri[b] = b;
+            HIPCHK(hipMalloc((void**)&s->step_rows, ri.size() * 4));
+            HIPCHK(hipMemcpyAsync(s->step_rows, ri.data(), ri.size() * 4, hipMemcpyHostToDevice, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+            HIPCHK(hipMalloc((void**)&s->step_logits, (size_t)s->max_streams * c.vocab * 4));
+            HIPCHK(hipMalloc((void**)&s->step_sym, (size_t)s->max_streams * 4));
+        }
     }
     return CZ_OK;
 }
@@ -530,7 +575,7 @@ static cz_status llama_step_any(cz_session* s, int B, int pos, int max_nk) {
 }
 // one token per stream at position `pos` (tokens in s->tok[0..B)); logits -> s->step_logits [B][V]
 static cz_status llama_step(cz_session* s, int B, int pos) {
-    if (pos >= CZ_MAX_CTX || pos >= s->llama.cfg.max_pos || (s->ctx_cap && pos >= (int)s->ctx_cap)) { cz_set_error("position %d exceeds the supported context (%d)", pos, CZ_MAX_CTX); return CZ_ERR_STATE; }
+    if (pos >= (int)cz_ctx_limit(s) || (s->ctx_cap && pos >= (int)s->ctx_cap)) { cz_set_error("position %d exceeds the context (max_position_embeddings %d, KV cache %zu)", pos, s->llama.cfg.max_pos, s->ctx_cap); return CZ_ERR_STATE; }
     hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, pos);
     if (!s->decode_v1 && s->llama.cfg.n_heads / s->llama.cfg.n_kv_heads <= 4) return llama_step_any(s, B, pos, pos + 1);
     if (B > 64) s->force_big_gemm = 1;                     // the general skinny kernel covers M <= 64 only
@@ -539,7 +584,7 @@ static cz_status llama_step(cz_session* s, int B, int pos) {
 }
 // re-prime: every stream forwards hl tokens (s->tok[b*hl + j]) at positions 0..hl-1 into its cache; logits of the last row
 static cz_status llama_reprime(cz_session* s, int B, int hl) {
-    if (hl <= 0 || hl > CZ_MAX_CTX || (s->ctx_cap && hl > (int)s->ctx_cap)) { cz_set_error("history length %d out of range", hl); return CZ_ERR_ARG; }
+    if (hl <= 0 || hl > (int)cz_ctx_limit(s) || (s->ctx_cap && hl > (int)s->ctx_cap)) { cz_set_error("history length %d out of range", hl); return CZ_ERR_ARG; }
     const size_t kvd = (size_t)s->llama.cfg.n_kv_heads * 64;
     std::vector<cz_seq_desc> sd(B), sq(B); std::vector<cz_rope_desc> rd(B); std::vector<int> ri(B);
     for (int b = 0; b < B; ++b) {
@@ -656,7 +701,7 @@ static cz_status encode_llama(cz_session* s, size_t n_streams, const uint32_t* c
     }
     for (auto& sg : segs) {
         size_t T = sg.end_i - sg.hist_start;
-        if (T > (size_t)CZ_MAX_CTX || T > (size_t)c.max_pos) { cz_set_error("segment of %zu positions exceeds the supported context (%d)", T, CZ_MAX_CTX); return CZ_ERR_STATE; }
+        if (T > cz_ctx_limit(s)) { cz_set_error("a segment of %zu positions exceeds max_position_embeddings = %d (the reference fails there too) / the kernels' %d", T, c.max_pos, CZ_KERNEL_MAX_CTX); return CZ_ERR_STATE; }
     }
     const int d = c.d_model, kvd = c.n_kv_heads * 64, nq = d + 2 * kvd;
     size_t si = 0;
@@ -753,7 +798,7 @@ static cz_status xe_llama(cz_session* s, size_t n_spans, const uint32_t* const* 
         sp[i].np = v.size();
         v.insert(v.end(), tgt[i], tgt[i] + nt - 1);                   // the last target is scored, never fed
         for (uint32_t t : v) if (t >= (uint32_t)c.vocab) { cz_set_error("token id %u >= vocab %d", t, c.vocab); return CZ_ERR_ARG; }
-        if (v.size() > (size_t)CZ_MAX_CTX || v.size() > (size_t)c.max_pos) { cz_set_error("span of %zu positions exceeds the supported context (%d)", v.size(), CZ_MAX_CTX); return CZ_ERR_STATE; }
+        if (v.size() > cz_ctx_limit(s)) { cz_set_error("span of %zu positions exceeds the supported context (%zu)", v.size(), cz_ctx_limit(s)); return CZ_ERR_STATE; }
     }
     const int d = c.d_model, kvd = c.n_kv_heads * 64, nq = d + 2 * kvd;
     size_t si = 0;
@@ -880,38 +925,43 @@ static cz_status decode_llama_begin(cz_session* s, int B, const uint8_t* const* 
     run.active = false;
     if (R == 0) { cz_set_error("reprime_interval must be > 0"); return CZ_ERR_ARG; }
     if (bos >= (uint32_t)c.vocab) { cz_set_error("bos id %u >= vocab", bos); return CZ_ERR_ARG; }
-    CZCHK(ensure_streams(s, B));
+    size_t max_tc_in = 0;
+    for (int b = 0; b < B; ++b) max_tc_in = std::max(max_tc_in, tcs[b]);
+    size_t ec = context_window > 0 ? context_window - 1 : 0; if (ec > 511) ec = 511;         // :2506
+    // longest context this run reaches (the schedule is known up front): it sizes the KV cache and the attention kernel's LDS inside the
+    // captured graph, and with it how many blocks of other lanes' kernels fit on a CU beside the attention blocks
+    size_t mx = 1;
+    {
+        size_t ip = 1;
+        for (size_t i = 0; i < max_tc_in; ++i) {
+            if (ip >= ec && (i % R) == 0 && i > 0) ip = i + 1 > ec ? ec : i + 1;
+            if (ip > mx) mx = ip;
+            ip += 1;
+        }
+    }
+    if (mx >= cz_ctx_limit(s)) {                       // (mx = the last position a step runs at)
+        cz_set_error("the re-prime schedule (context %u, interval %u, %zu tokens) reaches position %zu: beyond max_position_embeddings = %d (the reference fails there too) / the kernels' %d",
+                     context_window, R, max_tc_in, mx, c.max_pos, CZ_KERNEL_MAX_CTX);
+        return CZ_ERR_STATE;
+    }
+    CZCHK(ensure_streams(s, B, std::min(mx + 2, cz_ctx_limit(s))));
     CZCHK(cz_dec_run_setup(s, B, payloads, lens, caps, tcs));
     const size_t max_tc = run.max_tc;
     cz_dec_state* dst = (cz_dec_state*)s->decst.p;
     HIPCHK(cz_launch_dec_init(s->stream, dst, B));                                           // ArithmeticDecoder::new (:2485)
     hipLaunchKernelGGL(init_out_ids_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, dst, B, bos);
-    CZCHK(s->tok.ensure((size_t)B * CZ_MAX_CTX * 4));
-    {   // the captured step graph holds raw pointers: size the buffers of every later re-prime before it is built
-        size_t ec0 = context_window > 0 ? context_window - 1 : 0; if (ec0 > 511) ec0 = 511;
-        if (max_tc > R && ec0 > 0) CZCHK(reserve_rows(s, (size_t)B * ec0, (size_t)B));
-    }
+    CZCHK(s->tok.ensure((size_t)B * std::max<size_t>(ec, 64) * 4));
+    // the captured step graph holds raw pointers: size the buffers of every later re-prime before it is built
+    if (max_tc > R && ec > 0) CZCHK(reserve_rows(s, (size_t)B * ec, (size_t)B));
     hipLaunchKernelGGL(fill_u32_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, (uint32_t*)s->tok.p, bos, B);
     hipLaunchKernelGGL(fill_u32_kernel, dim3((B + 63) / 64), dim3(64), 0, s->stream, s->step_sym, bos, B);   // finished streams keep a valid id
     s->index_pos = 0;                                                                        // the single-stream step state is reset
     CZCHK(llama_step(s, B, 0));                                                              // step(bos) (:2485)
-    size_t ec = context_window > 0 ? context_window - 1 : 0; if (ec > 511) ec = 511;         // :2506
     // graph replay unless per-kernel profiling of the decode families is requested or the graph path is disabled
     const unsigned dec_kinds = (1u << PK_DECODE) | (1u << PK_DEC_GEMM) | (1u << PK_DEC_GEMM_QKV) | (1u << PK_DEC_GEMM_GU) | (1u << PK_DEC_GEMM_HEAD) | (1u << PK_DEC_ATTN) | (1u << PK_DEC_NORM) | (1u << PK_EMBED);
     const bool prof_decode = s->prof_on && (s->prof_mask & dec_kinds);
     const bool use_graph = !s->no_graph && !s->decode_v1 && !s->serial_cdf && !prof_decode && c.n_heads / c.n_kv_heads <= 4;
-    // longest context this run reaches (the schedule is known up front): it sizes the attention kernel's LDS inside the captured graph, and
-    // with it how many blocks of other lanes' kernels fit on a CU beside the attention blocks
-    int max_nk = 2;
-    {
-        size_t ip = 1, mx = 1;
-        for (size_t i = 0; i < max_tc; ++i) {
-            if (ip >= ec && (i % R) == 0 && i > 0) ip = i + 1 > ec ? ec : i + 1;
-            if (ip > mx) mx = ip;
-            ip += 1;
-        }
-        max_nk = (int)std::min<size_t>(mx + 2, CZ_MAX_CTX);
-    }
+    const int max_nk = (int)std::min<size_t>(mx + 2, s->ctx_cap);
     if (use_graph && (s->graph_B != B || s->graph_gen != s->devbuf_gen || s->graph_max_nk != max_nk)) {
         CZCHK(build_step_graph(s, B, max_nk));
         if (s->graph_gen != s->devbuf_gen) CZCHK(build_step_graph(s, B, max_nk));            // the dry run itself grew a buffer: capture again
@@ -954,7 +1004,7 @@ static cz_status decode_llama_advance(cz_session* s, size_t n) {
             index_pos = hl;
             hipLaunchKernelGGL(set_counters_kernel, dim3(1), dim3(1), 0, s->stream, s->pos_dev, (int)index_pos, (unsigned long long)i);
         }
-        if (index_pos >= (size_t)CZ_MAX_CTX || index_pos >= s->ctx_cap) { cz_set_error("position %zu exceeds the supported context (%d)", index_pos, CZ_MAX_CTX); run.active = false; return CZ_ERR_STATE; }
+        if (index_pos >= s->ctx_cap) { cz_set_error("position %zu exceeds the KV cache of this run (%zu)", index_pos, s->ctx_cap); run.active = false; return CZ_ERR_STATE; }
         if (run.use_graph) {
             if (s->probe_launch && i < 64) HIPCHK(hipStreamSynchronize(s->stream));          // probe: cost of a launch into an empty queue
             timespec c0, c1; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c0);
@@ -1021,8 +1071,9 @@ extern "C" cz_status cz_session_open(const cz_model_desc* desc, int device_ordin
         hipMalloc((void**)&s->cdf_scratch, cz_cdf_par_scratch_bytes(s->llama.cfg.vocab, 0)) != hipSuccess) { cz_set_error("cannot allocate CDF scratch"); rc = CZ_ERR_HIP; }
     if (rc == CZ_OK && desc->backend == CZ_BACKEND_RWKV7 && cz_cdf_par_supported((int)cz_rwkv7_vocab(s), 1) &&
         hipMalloc((void**)&s->cdf_scratch, cz_cdf_par_scratch_bytes((int)cz_rwkv7_vocab(s), 1)) != hipSuccess) { cz_set_error("cannot allocate CDF scratch"); rc = CZ_ERR_HIP; }
-    if (rc == CZ_OK && cz_dec_attn_prepare(CZ_MAX_CTX) != hipSuccess) { cz_set_error("cannot reserve LDS for decode attention"); rc = CZ_ERR_HIP; }
-    if (rc == CZ_OK && cz_attention_prepare(CZ_MAX_CTX) != hipSuccess) { cz_set_error("cannot reserve LDS for attention"); rc = CZ_ERR_HIP; }
+    if (rc == CZ_OK && cz_dec_attn_prepare(CZ_DEF_CTX) != hipSuccess) { cz_set_error("cannot reserve LDS for decode attention"); rc = CZ_ERR_HIP; }
+    if (rc == CZ_OK && cz_attention_prepare(CZ_DEF_CTX) != hipSuccess) { cz_set_error("cannot reserve LDS for attention"); rc = CZ_ERR_HIP; }
+    if (rc == CZ_OK && (cz_gemm_prepare() != hipSuccess || cz_gemm_mid_prepare() != hipSuccess || cz_dec_gemm_prepare() != hipSuccess)) { cz_set_error("cannot reserve LDS for the GEMM kernels"); rc = CZ_ERR_HIP; }
     if (rc != CZ_OK) { cz_session_close(s); return rc; }
     *out = s;
     return CZ_OK;
@@ -1045,9 +1096,7 @@ extern "C" void cz_session_close(cz_session* s) {
     if (s->dbg_g) hipGraphDestroy(s->dbg_g);
     s->prof_drain();
     for (auto e : s->evt_free) hipEventDestroy(e);
-    DevBuf* bufs[] = {&s->tok, &s->x, &s->xn, &s->qkv, &s->gu, &s->h, &s->seqd, &s->roped, &s->rowidx, &s->sym, &s->clo, &s->chi, &s->xl,
-                      &s->logits, &s->payload, &s->outids, &s->decst};
-    for (auto b : bufs) b->release();
+    for (DevBuf* b : s->all_bufs()) b->release();
     void* ptrs[] = {s->cdf_scratch, s->fallback_dev, s->llama.blob_gu, s->llama.blob_k2, s->llama.blob_dec, s->llama.blob, s->llama.rope_cos, s->llama.rope_sin, s->kvcache, s->pos_dev, s->step_seqd, s->step_roped, s->step_rows,
                     s->step_logits, s->step_sym};
     for (auto p : ptrs) if (p) { hipError_t e = hipFree(p); (void)e; }
@@ -1065,7 +1114,7 @@ extern "C" cz_status cz_step_logits(cz_session* s, uint32_t token, float* out_lo
     HIPCHK(hipSetDevice(s->device));
     if (s->backend == CZ_BACKEND_RWKV7) return cz_rwkv7_step_host(s, token, out_logits);
     if (token >= (uint32_t)s->llama.cfg.vocab) { cz_set_error("token id %u >= vocab %d", token, s->llama.cfg.vocab); return CZ_ERR_ARG; }
-    CZCHK(ensure_streams(s, 1));
+    CZCHK(ensure_streams(s, 1, s->index_pos + 1, true));        // (a stream that steps past its cache keeps its keys: the cache is re-laid out longer)
     CZCHK(s->tok.ensure(64));
     HIPCHK(hipMemcpyAsync(s->tok.p, &token, 4, hipMemcpyHostToDevice, s->stream));
     CZCHK(llama_step(s, 1, (int)s->index_pos));
@@ -1081,8 +1130,8 @@ extern "C" cz_status cz_reprime_logits(cz_session* s, const uint32_t* history, s
     HIPCHK(hipSetDevice(s->device));
     if (s->backend == CZ_BACKEND_RWKV7) return cz_rwkv7_reprime_host(s, history, n, out_logits);
     for (size_t i = 0; i < n; ++i) if (history[i] >= (uint32_t)s->llama.cfg.vocab) { cz_set_error("token id %u >= vocab", history[i]); return CZ_ERR_ARG; }
-    if (n > (size_t)CZ_MAX_CTX) { cz_set_error("history of %zu tokens exceeds the supported context (%d)", n, CZ_MAX_CTX); return CZ_ERR_STATE; }
-    CZCHK(ensure_streams(s, 1));
+    if (n > cz_ctx_limit(s)) { cz_set_error("history of %zu tokens exceeds max_position_embeddings = %d / the kernels' %d", n, s->llama.cfg.max_pos, CZ_KERNEL_MAX_CTX); return CZ_ERR_STATE; }
+    CZCHK(ensure_streams(s, 1, n));
     CZCHK(s->tok.ensure(n * 4));
     HIPCHK(hipMemcpyAsync(s->tok.p, history, n * 4, hipMemcpyHostToDevice, s->stream));
     s->index_pos = 0;                                                                       // fresh cache (src/models.rs:105-107)
@@ -1331,7 +1380,8 @@ extern "C" cz_status cz_profile_read(cz_session* s, cz_kernel_stat* out, size_t 
 }
 extern "C" cz_status cz_synchronize(cz_session* s) {
     if (!s) return CZ_ERR_ARG;
-    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());                     // the session's stream, its decode lanes' and its forks'
     return CZ_OK;
 }
 // tuning aid (tools/bench_decode_step.py): lock-step decode steps of B streams at a FIXED position `pos` (KV cache zeroed), as a replayed
@@ -1343,10 +1393,10 @@ extern "C" cz_status cz_debug_decode_steps(cz_session* s, int B, int pos, int it
     const cz_llama_config& c = s->llama.cfg;
     auto one = [&]() -> cz_status {
         if (with_symbol) HIPCHK(cz_launch_decode_symbol(s->stream, s->step_logits, c.vocab, (cz_dec_state*)s->decst.p, s->step_sym, B, c.vocab, 0, 0ull, s->fallback_dev, nullptr, s->cdf_scratch));
-        return llama_step_any(s, B, pos, use_graph ? (pos + 1 <= 1024 ? 1024 : CZ_MAX_CTX) : pos + 1);
+        return llama_step_any(s, B, pos, use_graph ? (pos + 1 <= 1024 ? 1024 : (pos + 1 <= CZ_DEF_CTX ? CZ_DEF_CTX : (int)s->ctx_cap)) : pos + 1);
     };
     if (iters <= 0) {
-        CZCHK(ensure_streams(s, B));
+        CZCHK(ensure_streams(s, B, pos >= 0 ? (size_t)pos + 1 : 0));
         if (pos < 0 || pos >= (int)s->ctx_cap) { cz_set_error("pos out of range"); return CZ_ERR_ARG; }
         CZCHK(s->tok.ensure((size_t)B * 4)); CZCHK(s->decst.ensure(B * sizeof(cz_dec_state))); CZCHK(s->payload.ensure((size_t)B * 64)); CZCHK(s->outids.ensure((size_t)B * 16));
         HIPCHK(hipMemsetAsync(s->kvcache, 0, (size_t)s->max_streams * s->kv_stream_stride * 4, s->stream));

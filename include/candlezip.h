@@ -215,7 +215,7 @@ typedef struct cz_kernel_stat {
 } cz_kernel_stat;
 cz_status cz_profile_enable(cz_session* s, int on);                       /* resets the accumulators */
 cz_status cz_profile_read(cz_session* s, cz_kernel_stat* out, size_t cap, size_t* n);
-/* device synchronise on the library's stream (bench brackets the timed region with it) */
+/* synchronise the session's device: its own stream, its decode lanes' and its forks' (bench brackets the timed region with it) */
 cz_status cz_synchronize(cz_session* s);
 
 #ifdef __cplusplus

@@ -101,14 +101,23 @@ def test_rmsnorm_bitexact(cz, czo, M, d):
     _assert_bitexact(Y, czo.rmsnorm_bf16w(X, w, 1e-5), "rmsnorm")
 
 
-@pytest.mark.parametrize("M,pos0,nh,nkv", [(1, 0, 9, 3), (1, 700, 9, 3), (40, 0, 9, 3), (130, 0, 2, 1), (3, 1000, 9, 3), (70, 64, 4, 4), (17, 63, 2, 1)])
-def test_attention_bitexact(cz, czo, M, pos0, nh, nkv):
+@pytest.mark.parametrize("M,pos0,nh,nkv,variant", [
+    (1, 0, 9, 3, 0), (1, 700, 9, 3, 0), (40, 0, 9, 3, 0), (130, 0, 2, 1, 0), (3, 1000, 9, 3, 0), (70, 64, 4, 4, 0), (17, 63, 2, 1, 0),
+    # BASELINE config 5's range (keys up to 1535 / 2048): one row at the sawtooth's peak, the register-resident kernel at its last chunk, v1's last keys
+    (1, 1535, 9, 3, 0), (3, 2040, 9, 3, 0), (511, 0, 9, 3, 0), (40, 1490, 9, 3, 0), (20, 2020, 2, 1, 0),
+    # the three-pass kernel (attention_v3_kernel): forced on shapes the others cover too, then past 2048 keys where it is the only one
+    (40, 0, 9, 3, 2), (70, 1500, 9, 3, 2), (33, 100, 4, 4, 2), (1, 300, 2, 1, 2), (5, 3000, 9, 3, 0), (300, 2500, 2, 1, 0), (1, 8191, 9, 3, 0), (17, 4090, 4, 1, 0)])
+def test_attention_bitexact(cz, czo, M, pos0, nh, nkv, variant):
     rng = np.random.default_rng(M + pos0)
     nk = pos0 + M
     Q = rng.standard_normal((M, nh * 64)).astype(np.float32)
     K = rng.standard_normal((nk, nkv * 64)).astype(np.float32); V = rng.standard_normal((nk, nkv * 64)).astype(np.float32)
     O = np.empty_like(Q)
-    rc = cz.lib().cz_debug_attention(Q.ctypes.data, K.ctypes.data, V.ctypes.data, O.ctypes.data, M, pos0, nh, nkv)
+    cz.lib().cz_debug_attn_variant(variant)
+    try:
+        rc = cz.lib().cz_debug_attention(Q.ctypes.data, K.ctypes.data, V.ctypes.data, O.ctypes.data, M, pos0, nh, nkv)
+    finally:
+        cz.lib().cz_debug_attn_variant(0)
     assert rc == 0, cz.lib().cz_last_error()
     _assert_bitexact(O, czo.attention_ref(Q, K, V, pos0, nh, nkv), "attention")
 

@@ -60,7 +60,7 @@ def test_bench_two_ranks_rehearsal():
     """bench.py's N > 1 path (work list -> LPT share per rank, barrier, max-over-ranks timing, one JSON line from rank 0) with two gloo ranks
     on GPU 0 and the tiny model; the driver runs the RCCL / multi-GPU case"""
     argv = ["bench.py", "--gpus", "2", "--tiny", "--streams", "6", "--lanes", "2", "--lane-streams", "3", "--sample-tokens", "1536", "--window", "512",
-            "--steps", "3", "--warmup", "1", "--profile-tokens", "64", "--cpu-sample", "0"]
+            "--steps", "3", "--warmup", "1", "--profile-tokens", "1024", "--cpu-sample", "0"]
     procs = []
     port = 27611 + os.getpid() % 500
     for r in range(2):
@@ -76,4 +76,20 @@ def test_bench_two_ranks_rehearsal():
     assert not any(l.startswith("{") for l in outs[1].splitlines())           # only rank 0 prints the line (gloo itself may chat on stdout)
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
     assert line["generations_verified"] >= 1                       # 3 windows of 512 = one whole 1536-token sample: round trip checked
-    assert "roofline" in line and line["config"]["streams_per_gpu"] == 6
+    assert "roofline" in line and line["config"]["streams_per_gpu"] == 6 and line["ranks_seen"] == 2 and line["windows_verified"] >= 3
+
+
+def test_bench_gpus_flag_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (no WORLD_SIZE in the environment) must not time one GPU and call it two: it starts
+    two fresh child ranks itself before touching the GPU; rank 0's line says how many ranks the process group really had"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(CZ_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    argv = ["bench.py", "--gpus", "2", "--tiny", "--streams", "4", "--lanes", "2", "--lane-streams", "2", "--sample-tokens", "1024", "--window", "512",
+            "--steps", "2", "--warmup", "0", "--profile-tokens", "0", "--cpu-sample", "0"]
+    r = subprocess.run([sys.executable, *argv], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["dist_backend"] == "gloo" and line["value"] > 0
+    assert line["windows_verified"] >= 2
