@@ -67,6 +67,7 @@ struct cz_session {
     size_t max_batch_rows = 98304, logit_batch_rows = 8192;
     int force_big_gemm = 0, serial_cdf = 0, decode_v1 = 0, no_graph = 0, fuse_norm = 0, step_sync = 0, dbg_skip = 0, wide_min_streams = 256, wide_mode = 3;
     hipGraph_t dbg_g = nullptr; hipGraphExec_t dbg_ge = nullptr;      // cz_debug_decode_steps
+    int rwkv_seq = 1;                   // 1 = RWKV7 encode is sequence-parallel (rw_encode_seq_group); 0 = the lock-step token-by-token walk (cz_rwkv7_encode_group)
     int no_last_prune = 0;              // test knob: 1 = the last layer's tail on every row (llama_body)
     int stream_prio = 0;                // HIP priority of this session's stream and of the decode lanes it makes (cz_debug_set "stream_priority")
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; int graph_B = 0, graph_max_nk = 0; unsigned long long graph_gen = 0;
@@ -106,6 +107,7 @@ size_t cz_rwkv7_vocab(const cz_session* s);
 cz_status cz_rwkv7_step_host(cz_session* s, uint32_t token, float* out_logits);
 cz_status cz_rwkv7_reprime_host(cz_session* s, const uint32_t* hist, size_t n, float* out_logits);
 cz_status cz_rwkv7_make_lane(const cz_session* parent, cz_session* child);
+cz_status cz_rwkv7_encode_seq(cz_session* s, size_t n_streams, const uint32_t* const* ids, const size_t* n, uint32_t* const* lo, uint32_t* const* hi);
 cz_status cz_rwkv7_encode_group(cz_session* s, int B, const uint32_t* const* ids, const size_t* n, uint32_t* const* lo, uint32_t* const* hi);
 cz_status cz_rwkv7_decode_begin(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* caps, const size_t* tcs, uint32_t bos);
 // session.hip: payload buffer / decoder states of a lock-step group, shared by both back-ends

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restr
     }
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     if (EPI == 1) {
-        static_assert(EPI == 0 || TN == 2, "the SwiGLU epilogue pairs the two column tiles of a wave");
+        static_assert(EPI != 1 || TN == 2, "the SwiGLU epilogue pairs the two column tiles of a wave");
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int hcol = (bn * BN + wn * TN * 32) / 2 + lr;
@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = bm * BM + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float v = R ? tot[i][j][r] + rv[r] : tot[i][j][r];
+                float v = R ? tot[i][j][r] + rv[r] : tot[i][j][r];
+                if (EPI == 2) { const float z = tot[i][j][r] > 0.0f ? tot[i][j][r] : 0.0f; v = z * z; }     // RWKV7 channel-mix key: relu(x)^2 (rwkv7.rs:426)
                 if (row < M) C[(size_t)row * ldc + col] = v;
             }
         }
@@ -255,6 +256,9 @@ hipError_t cz_gemm_prepare() {
     if (e == hipSuccess) e = big_prepare<64, 64, 0>();
     if (e == hipSuccess) e = big_prepare<128, 128, 0>();
     if (e == hipSuccess) e = big_prepare<128, 64, 0>();
+    if (e == hipSuccess) e = big_prepare<64, 64, 2>();
+    if (e == hipSuccess) e = big_prepare<128, 128, 2>();
+    if (e == hipSuccess) e = big_prepare<128, 64, 2>();
     return e;
 }
 
@@ -301,4 +305,12 @@ hipError_t cz_launch_gemm(hipStream_t st, const float* A, int lda, const uint16_
     if (M <= g_gemm_mid_rows && (long)((M + 127) / 128) * (N / 64) < 512) return launch_big<64, 64, 2, 2>(st, A, lda, W, C, ldc, R, ldr, M, N, K);
     if (N % 128 == 0) return launch_big<128, 128, 2, 2>(st, A, lda, W, C, ldc, R, ldr, M, N, K);
     return launch_big<128, 64, 2, 2>(st, A, lda, W, C, ldc, R, ldr, M, N, K);
+}
+// C[M][N] = relu(A . W^T)^2 on the tiled kernel, any M (the RWKV7 channel-mix key projection of a sequence-parallel encode)
+hipError_t cz_launch_gemm_relusq(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, int M, int N, int K) {
+    if (M <= 0) return hipSuccess;
+    if (K % 64 != 0 || N % 64 != 0) return hipErrorInvalidValue;
+    if (M <= g_gemm_mid_rows && (long)((M + 127) / 128) * (N / 64) < 512) return launch_big<64, 64, 2, 2, 2>(st, A, lda, W, C, ldc, nullptr, 0, M, N, K);
+    if (N % 128 == 0) return launch_big<128, 128, 2, 2, 2>(st, A, lda, W, C, ldc, nullptr, 0, M, N, K);
+    return launch_big<128, 64, 2, 2, 2>(st, A, lda, W, C, ldc, nullptr, 0, M, N, K);
 }

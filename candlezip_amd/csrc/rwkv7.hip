@@ -34,6 +34,8 @@ __host__ __device__ __forceinline__ int kq_idx(int k) { return (k & ~63) | ((k &
 struct RwLayer {
     // matrices, kq-packed bf16 [N][K]
     uint16_t *r, *k, *v, *o, *w1, *w2, *a1, *a2, *v1, *v2, *g1, *g2, *fk, *fv;
+    // the same matrices in natural k order, [pad64(N)][pad64(K)] zero-padded: operands of the tiled big-M GEMM (sequence-parallel encode)
+    uint16_t *r_n, *k_n, *v_n, *o_n, *w1_n, *w2_n, *a1_n, *a2_n, *v1_n, *v2_n, *g1_n, *g2_n, *fk_n, *fv_n;
     // vectors (bf16)
     uint16_t *pre_w, *pre_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b, *gn_w, *gn_b, *x_r, *x_w, *x_k, *x_v, *x_a, *x_g, *w0, *a0, *v0, *k_k, *k_a,
         *r_k, *fx_k;
@@ -42,7 +44,7 @@ struct RwLayer {
 struct Rwkv7Model {
     cz_rwkv7_config cfg{};
     std::vector<void*> allocs;
-    uint16_t *emb = nullptr, *head = nullptr, *lno_w = nullptr, *lno_b = nullptr;
+    uint16_t *emb = nullptr, *head = nullptr, *head_n = nullptr, *lno_w = nullptr, *lno_b = nullptr;
     std::vector<RwLayer> L;
     // per-stream state [L][B][...]
     int B = 0;
@@ -55,6 +57,9 @@ struct Rwkv7Model {
     // lock-step loops under hipGraph replay: one executable graph per loop kind, per-iteration scalars in HBM (step_dev)
     struct Graph { hipGraph_t g = nullptr; hipGraphExec_t e = nullptr; int B = 0; unsigned long long gen = ~0ull; } genc, gdec;
     unsigned long long* step_dev = nullptr;
+    // sequence-parallel encode (rw_encode_seq): packed-row work buffers, grown on demand
+    DevBuf q_x, q_xa, q_mix, q_p, q_tl, q_l2, q_sc, q_vf, q_y, q_ffk, q_idx, q_xn;
+    std::vector<DevBuf*> seq_bufs() { return {&q_x, &q_xa, &q_mix, &q_p, &q_tl, &q_l2, &q_sc, &q_vf, &q_y, &q_ffk, &q_idx, &q_xn}; }
 };
 
 // ------------------------------------------------------------------ kernels
@@ -67,6 +72,14 @@ __global__ void rw_pack_kernel(const uint16_t* __restrict__ W, uint16_t* __restr
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < N * (size_t)Kp; i += (size_t)gridDim.x * blockDim.x) {
         const size_t n = i / Kp; const int k = (int)(i % Kp);
         Wd[n * Kp + kq_idx(k)] = k < K ? W[n * K + k] : (uint16_t)0;
+    }
+}
+
+// Wn[n][k] = W[n][k] for n < N, k < K, else 0  ([Np][Kp], natural k order)
+__global__ void rw_pad_kernel(const uint16_t* __restrict__ W, uint16_t* __restrict__ Wn, size_t N, int K, size_t Np, int Kp) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < Np * (size_t)Kp; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / Kp; const int k = (int)(i % Kp);
+        Wn[i] = (n < N && k < K) ? W[n * K + k] : (uint16_t)0;
     }
 }
 
@@ -176,11 +189,13 @@ __global__ __launch_bounds__(64) void rw_state_kernel(const float* __restrict__ 
     __syncthreads();
     kk[i] = kkn; av[i] = a; kv[i] = k; wv[i] = w; rv[i] = r; vv[i] = v;
     __syncthreads();
-    float* Srow = S + (((size_t)b * gridDim.y + h) * 64 + i) * 64;
+    // state tile of a head in HBM: element (i, j) at ((j >> 2) * 64 + i) * 4 + (j & 3) — lane i's sixteen 16-B pieces of ITS row sit 1 KB apart,
+    // so load / store j4 moves one contiguous KB per wave (row-major rows of 256 B would be 64 lanes in 64 different rows: ~17x slower, guide)
+    float* Srow = S + ((size_t)b * gridDim.y + h) * 4096 + (size_t)i * 4;
     float srow[64];
 #pragma unroll
     for (int j4 = 0; j4 < 16; ++j4) {
-        const float4 t4 = *reinterpret_cast<const float4*>(Srow + 4 * j4);
+        const float4 t4 = *reinterpret_cast<const float4*>(Srow + 256 * j4);
         srow[4 * j4] = t4.x; srow[4 * j4 + 1] = t4.y; srow[4 * j4 + 2] = t4.z; srow[4 * j4 + 3] = t4.w;
     }
     float t = 0.0f;
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(64) void rw_state_kernel(const float* __restrict__ 
     }
     if (!mask || mask[b]) {
 #pragma unroll
-        for (int j4 = 0; j4 < 16; ++j4) *reinterpret_cast<float4*>(Srow + 4 * j4) = make_float4(srow[4 * j4], srow[4 * j4 + 1], srow[4 * j4 + 2], srow[4 * j4 + 3]);
+        for (int j4 = 0; j4 < 16; ++j4) *reinterpret_cast<float4*>(Srow + 256 * j4) = make_float4(srow[4 * j4], srow[4 * j4 + 1], srow[4 * j4 + 2], srow[4 * j4 + 3]);
     }
     yv[i] = y;
     __syncthreads();
@@ -318,11 +333,14 @@ cz_status cz_rwkv7_build(cz_session* s, const cz_model_desc* desc) {
         cz_set_error("tensor %s not found in the safetensors files", name.c_str());
         return CZ_ERR_IO;
     };
-    auto mat = [&](const std::string& name, uint16_t** out, int N, int K, float stdv) -> cz_status {
-        const int Kp = pad64(K);
+    auto mat = [&](const std::string& name, uint16_t** out, uint16_t** out_nat, int N, int K, float stdv) -> cz_status {
+        const int Kp = pad64(K), Np = pad64(N);
         CZCHK(rw_alloc(m, (void**)out, (size_t)N * Kp * 2));
+        CZCHK(rw_alloc(m, (void**)out_nat, (size_t)Np * Kp * 2));
         CZCHK(fetch(name, tmp, (size_t)N * K, stdv, 0.0f));
         hipLaunchKernelGGL(rw_pack_kernel, dim3(1024), dim3(256), 0, s->stream, tmp, *out, (size_t)N, K, Kp);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(rw_pad_kernel, dim3(1024), dim3(256), 0, s->stream, tmp, *out_nat, (size_t)N, K, (size_t)Np, Kp);
         HIPCHK(hipGetLastError());
         // `tmp` is reused by the next matrix.  Synthetic tensors are generated on s->stream (ordered behind this kernel), but a checkpoint
         // tensor arrives by a blocking hipMemcpy on the null stream, which a non-blocking stream does not wait for: drain the pack first
@@ -343,27 +361,27 @@ cz_status cz_rwkv7_build(cz_session* s, const cz_model_desc* desc) {
         if (i == 0) { CZCHK(vec(p + "pre_norm.weight", &l.pre_w, C, 0.1f, 1.0f)); CZCHK(vec(p + "pre_norm.bias", &l.pre_b, C, 0.02f, 0.0f)); }
         CZCHK(vec(p + "attn_norm.weight", &l.ln1_w, C, 0.1f, 1.0f)); CZCHK(vec(p + "attn_norm.bias", &l.ln1_b, C, 0.02f, 0.0f));
         CZCHK(vec(p + "ffn_norm.weight", &l.ln2_w, C, 0.1f, 1.0f));  CZCHK(vec(p + "ffn_norm.bias", &l.ln2_b, C, 0.02f, 0.0f));
-        CZCHK(mat(p + "attn.r_proj.weight", &l.r, C, C, 0.03f)); CZCHK(mat(p + "attn.k_proj.weight", &l.k, C, C, 0.03f));
-        CZCHK(mat(p + "attn.v_proj.weight", &l.v, C, C, 0.03f)); CZCHK(mat(p + "attn.o_proj.weight", &l.o, C, C, 0.03f));
+        CZCHK(mat(p + "attn.r_proj.weight", &l.r, &l.r_n, C, C, 0.03f)); CZCHK(mat(p + "attn.k_proj.weight", &l.k, &l.k_n, C, C, 0.03f));
+        CZCHK(mat(p + "attn.v_proj.weight", &l.v, &l.v_n, C, C, 0.03f)); CZCHK(mat(p + "attn.o_proj.weight", &l.o, &l.o_n, C, C, 0.03f));
         CZCHK(vec(p + "attn.g_norm.weight", &l.gn_w, C, 0.1f, 1.0f)); CZCHK(vec(p + "attn.g_norm.bias", &l.gn_b, C, 0.02f, 0.0f));
         CZCHK(vec(p + "attn.x_r", &l.x_r, C, 0.15f, 0.5f)); CZCHK(vec(p + "attn.x_w", &l.x_w, C, 0.15f, 0.5f)); CZCHK(vec(p + "attn.x_k", &l.x_k, C, 0.15f, 0.5f));
         CZCHK(vec(p + "attn.x_v", &l.x_v, C, 0.15f, 0.5f)); CZCHK(vec(p + "attn.x_a", &l.x_a, C, 0.15f, 0.5f)); CZCHK(vec(p + "attn.x_g", &l.x_g, C, 0.15f, 0.5f));
-        CZCHK(mat(p + "attn.w_lora.lora.0.weight", &l.w1, c.decay_rank, C, 0.05f)); CZCHK(mat(p + "attn.w_lora.lora.2.weight", &l.w2, C, c.decay_rank, 0.05f));
+        CZCHK(mat(p + "attn.w_lora.lora.0.weight", &l.w1, &l.w1_n, c.decay_rank, C, 0.05f)); CZCHK(mat(p + "attn.w_lora.lora.2.weight", &l.w2, &l.w2_n, C, c.decay_rank, 0.05f));
         CZCHK(vec(p + "attn.w_lora.lora.2.bias", &l.w0, C, 1.0f, 0.0f));
-        CZCHK(mat(p + "attn.a_lora.lora.0.weight", &l.a1, c.a_rank, C, 0.05f)); CZCHK(mat(p + "attn.a_lora.lora.2.weight", &l.a2, C, c.a_rank, 0.05f));
+        CZCHK(mat(p + "attn.a_lora.lora.0.weight", &l.a1, &l.a1_n, c.a_rank, C, 0.05f)); CZCHK(mat(p + "attn.a_lora.lora.2.weight", &l.a2, &l.a2_n, C, c.a_rank, 0.05f));
         CZCHK(vec(p + "attn.a_lora.lora.2.bias", &l.a0, C, 0.5f, 0.0f));
         if (i > 0) {                                                    // rwkv7.rs:146-152 (`contains_tensor`): the synthetic model mirrors the oracle
             l.has_v = 1;
-            CZCHK(mat(p + "attn.v_lora.lora.0.weight", &l.v1, c.v_rank, C, 0.05f)); CZCHK(mat(p + "attn.v_lora.lora.2.weight", &l.v2, C, c.v_rank, 0.05f));
+            CZCHK(mat(p + "attn.v_lora.lora.0.weight", &l.v1, &l.v1_n, c.v_rank, C, 0.05f)); CZCHK(mat(p + "attn.v_lora.lora.2.weight", &l.v2, &l.v2_n, C, c.v_rank, 0.05f));
             CZCHK(vec(p + "attn.v_lora.lora.2.bias", &l.v0, C, 0.5f, 1.0f));
         }
-        CZCHK(mat(p + "attn.g_lora.lora.0.weight", &l.g1, c.gate_rank, C, 0.05f)); CZCHK(mat(p + "attn.g_lora.lora.2.weight", &l.g2, C, c.gate_rank, 0.05f));
+        CZCHK(mat(p + "attn.g_lora.lora.0.weight", &l.g1, &l.g1_n, c.gate_rank, C, 0.05f)); CZCHK(mat(p + "attn.g_lora.lora.2.weight", &l.g2, &l.g2_n, C, c.gate_rank, 0.05f));
         CZCHK(vec(p + "attn.k_k", &l.k_k, C, 0.1f, 0.85f)); CZCHK(vec(p + "attn.k_a", &l.k_a, C, 0.1f, 1.0f)); CZCHK(vec(p + "attn.r_k", &l.r_k, C, 0.05f, 0.0f));
         CZCHK(vec(p + "ffn.x_k", &l.fx_k, C, 0.15f, 0.5f));
-        CZCHK(mat(p + "ffn.key.weight", &l.fk, F, C, 0.03f)); CZCHK(mat(p + "ffn.value.weight", &l.fv, C, F, 0.03f));
+        CZCHK(mat(p + "ffn.key.weight", &l.fk, &l.fk_n, F, C, 0.03f)); CZCHK(mat(p + "ffn.value.weight", &l.fv, &l.fv_n, C, F, 0.03f));
     }
     CZCHK(vec("model.norm.weight", &m->lno_w, C, 0.1f, 1.0f)); CZCHK(vec("model.norm.bias", &m->lno_b, C, 0.02f, 0.0f));
-    CZCHK(mat("lm_head.weight", &m->head, V, C, desc->synthetic_embed_std));
+    CZCHK(mat("lm_head.weight", &m->head, &m->head_n, V, C, desc->synthetic_embed_std));
     HIPCHK(hipStreamSynchronize(s->stream));
     return CZ_OK;
 }
@@ -375,6 +393,7 @@ static void rw_graph_destroy(Rwkv7Model::Graph& G) {
 void cz_rwkv7_destroy(cz_session* s) {
     if (!s->rwkv) return;
     rw_graph_destroy(s->rwkv->genc); rw_graph_destroy(s->rwkv->gdec);
+    for (DevBuf* b : s->rwkv->seq_bufs()) b->release();
     for (auto p : s->rwkv->allocs) { hipError_t e = hipFree(p); (void)e; }
     delete s->rwkv; s->rwkv = nullptr;
 }
@@ -523,7 +542,7 @@ static cz_status rw_graph_build(cz_session* s, Rwkv7Model::Graph& G, int B, F bo
 cz_status cz_rwkv7_make_lane(const cz_session* parent, cz_session* child) {
     const Rwkv7Model* pm = parent->rwkv;
     Rwkv7Model* m = new Rwkv7Model();
-    m->cfg = pm->cfg; m->emb = pm->emb; m->head = pm->head; m->lno_w = pm->lno_w; m->lno_b = pm->lno_b; m->L = pm->L;
+    m->cfg = pm->cfg; m->emb = pm->emb; m->head = pm->head; m->head_n = pm->head_n; m->lno_w = pm->lno_w; m->lno_b = pm->lno_b; m->L = pm->L;
     child->rwkv = m;                                               // m->allocs stays empty: cz_rwkv7_destroy frees the lane's own buffers only
     return CZ_OK;
 }
@@ -598,6 +617,324 @@ cz_status cz_rwkv7_encode_group(cz_session* s, int B, const uint32_t* const* ids
         for (int b = 0; b < B; ++b)
             for (size_t i = 0; i + 1 < n[g0 + b]; ++i) { lo[g0 + b][i] = hlo[i * B + b]; hi[g0 + b][i] = hhi[i * B + b]; }
     }
+    return CZ_OK;
+}
+
+// ------------------------------------------------------------------ sequence-parallel encode
+// Encode is teacher-forced: every token a stream will feed the model is known up front.  RWKV7's only recurrence in t is the WKV state
+// S_t = f(S_{t-1}, w_t, k_t, v_t, a_t) (rwkv7.rs:289-301) and the one-token shift of the LayerNorm'd input (:193-203, :414-425) — and
+// the latter needs x_{t-1} of the SAME layer, which is available for all t as soon as the layer below has run for all t.  So per
+// layer ALL T tokens of all streams go through the token-shift mixes and every projection as big-M GEMMs on the tiled MFMA kernel
+// (bit-identical to the T == 1 step: an output element's reduction order depends on K only), the state-independent per-token terms
+// (decay w, in-context rate a, normalised kk, k, the v-residual mix) are evaluated in parallel over (row, head), and only the scan
+// S_t, y_t = S_t r_t runs sequentially in t: one wave per (stream, head) with its 64 x 64 state tile in registers for the whole block —
+// the state never touches HBM between tokens (the lock-step step moves 2 x 16 KB per head, layer and token).  GroupNorm, bonus and gate
+// of y_t do not feed the recurrence and run in parallel again.  Literal symbols (id >= vocab) are coded but never step the model
+// (src/main.rs:2347): the model's row sequence is the stream's tokens with the literals removed, and a coded symbol reads the logits of
+// the last row at or before it.
+struct RwMixW { const uint16_t* w[6]; };
+// rows [M][C]: Y[r] = LayerNorm(X[src(r)]) ; pre_w != nullptr (layer 0): X[r] = pre-LayerNorm(X[r]) in place first (rwkv7.rs:468-470)
+__global__ void rw_seq_ln_kernel(float* __restrict__ X, const int* __restrict__ rows, const uint16_t* pre_w, const uint16_t* pre_b, const uint16_t* w, const uint16_t* b,
+                                 float eps, float* __restrict__ Y) {
+    extern __shared__ float sh[];
+    const int r = blockIdx.x, tid = threadIdx.x, C = blockDim.x;
+    const size_t src = rows ? (size_t)rows[r] : (size_t)r;
+    float x = X[src * C + tid];
+    if (pre_w) { x = block_layer_norm(x, pre_w, pre_b, eps, sh); X[src * C + tid] = x; }
+    Y[(size_t)r * C + tid] = block_layer_norm(x, w, b, eps, sh);
+}
+// token-shift mixes (rwkv7.rs:193-203 / :419-424): out_j[r] = xa + (prev - xa) * w_j, prev = the LayerNorm'd row before r in its stream:
+// row_prev[r] >= 0 -> XA[row_prev[r]] (inside this block), < 0 -> the stream's carry row -1 - row_prev[r] (state.att_x_prev / ffn_x_prev)
+template <int NMIX>
+__global__ void rw_seq_mix_kernel(const float* __restrict__ XA, const int* __restrict__ row_prev, const float* __restrict__ carry, RwMixW mw,
+                                  float* __restrict__ MIX, size_t mix_stride) {
+    const int r = blockIdx.x, tid = threadIdx.x, C = blockDim.x;
+    const float xa = XA[(size_t)r * C + tid];
+    const int pr = row_prev[r];
+    const float prev = pr >= 0 ? XA[(size_t)pr * C + tid] : carry[(size_t)(-1 - pr) * C + tid];
+    const float xx = prev - xa;
+#pragma unroll
+    for (int j = 0; j < NMIX; ++j) MIX[(size_t)j * mix_stride + (size_t)r * C + tid] = xa + xx * cz_bf16_to_f32(mw.w[j][tid]);
+}
+// carry[stream] = XA[last row of the stream in this block]
+__global__ void rw_seq_carry_kernel(const float* __restrict__ XA, const int* __restrict__ s_row0, const int* __restrict__ s_len, const int* __restrict__ s_stream,
+                                    float* __restrict__ carry) {
+    const int k = blockIdx.x, tid = threadIdx.x, C = blockDim.x;
+    carry[(size_t)s_stream[k] * C + tid] = XA[(size_t)(s_row0[k] + s_len[k] - 1) * C + tid];
+}
+// LoRA hidden activations (rwkv7.rs:211, 229, 235, 244), natural layout, zero-padded to the 64-multiples the GEMMs take: TL[r] = tanh(w1.) | a1. | sigmoid(g1.) | v1.
+__global__ void rw_seq_lora_act_kernel(const float* __restrict__ P, int ldp, int ow, int oa, int og, int ov, int rw, int ra, int rg, int rv,
+                                       float* __restrict__ TL, int pw, int pa, int pg, int pv) {
+    const int r = blockIdx.x, t = threadIdx.x;
+    const float* p = P + (size_t)r * ldp;
+    float* tl = TL + (size_t)r * (pw + pa + pg + pv);
+    if (t < pw) tl[t] = t < rw ? cz_tanhf(p[ow + t]) : 0.0f;
+    if (t < pa) tl[pw + t] = t < ra ? p[oa + t] : 0.0f;
+    if (t < pg) tl[pw + pa + t] = t < rg ? cz_sigmoidf(p[og + t]) : 0.0f;
+    if (t < pv) tl[pw + pa + pg + t] = t < rv ? p[ov + t] : 0.0f;
+}
+// per (row, head): everything of the time-mix that does not depend on the state (rwkv7.rs:213-266): SC[r][h] = kk | kk*a | w | k | r | v  (6 x 64 floats)
+#define RW_SC 384
+__global__ __launch_bounds__(64) void rw_seq_pre_kernel(const float* __restrict__ P, int ldp, const float* __restrict__ L2 /*[M][4C]: w a g nu*/, const RwLayer L, int layer, int C,
+                                                        float* __restrict__ VF /*[M][C]: layer 0's v*/, float* __restrict__ SC) {
+    __shared__ float kk[64];
+    const int r = blockIdx.x, h = blockIdx.y, i = threadIdx.x, c = h * 64 + i, H = gridDim.y;
+    const float* p = P + (size_t)r * ldp;
+    const float* l2 = L2 + (size_t)r * 4 * C;
+    const float rr = p[c], kraw = p[C + c];
+    float v = p[2 * C + c];
+    const float wc = l2[c] + cz_bf16_to_f32(L.w0[c]);
+    const float sp = cz_logf(cz_expf(-wc) + 1.0f);
+    const float wt = (-sp) + (-0.5f);
+    const float w = cz_expf(-cz_expf(wt));
+    const float a = cz_sigmoidf(l2[C + c] + cz_bf16_to_f32(L.a0[c]));
+    if (layer == 0) VF[(size_t)r * C + c] = v;
+    else if (L.has_v) {
+        const float nu = cz_sigmoidf(l2[3 * C + c] + cz_bf16_to_f32(L.v0[c]));
+        const float dl = VF[(size_t)r * C + c] - v;
+        v = v + dl * nu;
+    }
+    const float kk0 = kraw * cz_bf16_to_f32(L.k_k[c]);
+    kk[i] = kk0;
+    __syncthreads();
+    float ss = 0.0f;
+    for (int j = 0; j < 64; ++j) { const float q = kk[j] * kk[j]; ss = ss + q; }
+    float nrm = sqrtf(ss);
+    if (!(nrm > 1e-12f)) nrm = 1e-12f;
+    const float kkn = kk0 / nrm;
+    const float sc = 1.0f + (a - 1.0f) * cz_bf16_to_f32(L.k_a[c]);
+    const float k = kraw * sc;
+    float* o = SC + ((size_t)r * H + h) * RW_SC;
+    o[i] = kkn; o[64 + i] = kkn * a; o[128 + i] = w; o[192 + i] = k; o[256 + i] = rr; o[320 + i] = v;
+}
+// the scan: block = (active stream, head), one wave, lane i = state row i held in 64 registers for the stream's whole block of rows
+// (rwkv7.rs:289-301): t = S kk ; S' = S diag(w) - t (kk a)^T + v k^T ; y = S' r.  The next row's six vectors are in flight while a row is computed.
+__global__ __launch_bounds__(64) void rw_seq_scan_kernel(const float* __restrict__ SC, const int* __restrict__ s_row0, const int* __restrict__ s_len, const int* __restrict__ s_stream,
+                                                         float* __restrict__ S, float* __restrict__ Y, int C) {
+    __shared__ __attribute__((aligned(16))) float bc[2][5][64];
+    const int k = blockIdx.x, h = blockIdx.y, i = threadIdx.x, H = gridDim.y;
+    const int b = s_stream[k], row0 = s_row0[k], len = s_len[k];
+    float* Srow = S + ((size_t)b * H + h) * 4096 + (size_t)i * 4;          // tiled state (see rw_state_kernel)
+    float srow[64];
+#pragma unroll
+    for (int j4 = 0; j4 < 16; ++j4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(Srow + 256 * j4);
+        srow[4 * j4] = t4.x; srow[4 * j4 + 1] = t4.y; srow[4 * j4 + 2] = t4.z; srow[4 * j4 + 3] = t4.w;
+    }
+    const float* sc = SC + ((size_t)row0 * H + h) * RW_SC + i;
+    float nx[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) nx[q] = sc[64 * q];
+    for (int t = 0; t < len; ++t) {
+        float cur[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) cur[q] = nx[q];
+        if (t + 1 < len) {
+            const float* sn_ = sc + (size_t)(t + 1) * H * RW_SC;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) nx[q] = sn_[64 * q];
+        }
+        float (*B)[64] = bc[t & 1];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) B[q][i] = cur[q];
+        __syncthreads();                                                   // (one wave: the LDS writes above are visible to every lane's reads below)
+        const float v = cur[5];
+        float tt = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) tt = cz_fma(srow[j], B[0][j], tt);                           // (S @ kk)[i]
+        float y = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const float sn = (srow[j] * B[2][j] - tt * B[1][j]) + v * B[3][j];
+            srow[j] = sn;
+            y = cz_fma(sn, B[4][j], y);                                                           // (S' @ r)[i]
+        }
+        Y[(size_t)(row0 + t) * C + h * 64 + i] = y;
+    }
+#pragma unroll
+    for (int j4 = 0; j4 < 16; ++j4) *reinterpret_cast<float4*>(Srow + 256 * j4) = make_float4(srow[4 * j4], srow[4 * j4 + 1], srow[4 * j4 + 2], srow[4 * j4 + 3]);
+}
+// per (row, head): GroupNorm of y (rwkv7.rs:303, 529-542), bonus (r . k r_k) v (:305-321), gate (:323) -> OUT[r][c], natural layout
+__global__ __launch_bounds__(64) void rw_seq_post_kernel(const float* __restrict__ Y, const float* __restrict__ SC, const float* __restrict__ L2, const RwLayer L, int C,
+                                                         float* __restrict__ OUT) {
+    __shared__ float yv[64], rv[64], kv[64];
+    const int r = blockIdx.x, h = blockIdx.y, i = threadIdx.x, c = h * 64 + i, H = gridDim.y;
+    const float* sc = SC + ((size_t)r * H + h) * RW_SC;
+    const float y = Y[(size_t)r * C + c], v = sc[320 + i], g = L2[(size_t)r * 4 * C + 2 * C + c];
+    yv[i] = y; rv[i] = sc[256 + i]; kv[i] = sc[192 + i];
+    __syncthreads();
+    float s1 = 0.0f;
+    for (int j = 0; j < 64; ++j) s1 = s1 + yv[j];
+    const float mean = s1 * 0.015625f;
+    const float cen = y - mean;
+    __syncthreads();
+    yv[i] = cen * cen;
+    __syncthreads();
+    float s2 = 0.0f, al = 0.0f;
+    for (int j = 0; j < 64; ++j) s2 = s2 + yv[j];
+    for (int j = 0; j < 64; ++j) { const float q = rv[j] * kv[j] * cz_bf16_to_f32(L.r_k[h * 64 + j]); al = al + q; }
+    const float den = sqrtf(s2 * 0.015625f + (float)64e-5);
+    const float gn = cen / den * cz_bf16_to_f32(L.gn_w[c]) + cz_bf16_to_f32(L.gn_b[c]);
+    const float ad = al * v;
+    OUT[(size_t)r * C + c] = (gn + ad) * g;
+}
+
+int g_rw_seq_rows = 32768;     // tuning knob (cz_debug_set "rwkv_seq_rows"): rows (model steps of all streams) per time block of the sequence-parallel encode
+
+// Streams [0, B) of one group (B <= max_streams: the recurrent state arrays have that many slots).  Coder intervals straight into lo / hi.
+static cz_status rw_encode_seq_group(cz_session* s, int B, const uint32_t* const* ids, const size_t* n, uint32_t* const* lo, uint32_t* const* hi) {
+    Rwkv7Model* m = s->rwkv; const cz_rwkv7_config& c = m->cfg;
+    const uint32_t V = (uint32_t)c.vocab;
+    const int C = c.hidden, F = c.d_ffn, H = C / 64, Bc = s->max_streams, L = c.n_layers;
+    const int pw = pad64(c.decay_rank), pa = pad64(c.a_rank), pg = pad64(c.gate_rank), pv = pad64(c.v_rank), ptl = pw + pa + pg + pv;
+    const int ow = 3 * C, oa = ow + pw, og = oa + pa, ov = og + pg, ldp = ov + pv;
+    hipStream_t st = s->stream;
+    CZCHK(rw_ensure_streams(s, B));
+    CZCHK(rw_reset(s));
+    // the model's row sequence per stream, and for every coded symbol i the row whose logits code it
+    std::vector<std::vector<uint32_t>> toks(B); std::vector<std::vector<uint32_t>> rowof(B);
+    size_t max_steps = 0;
+    for (int b = 0; b < B; ++b) {
+        if (n[b] == 0) { cz_set_error("stream %d is empty (ids must start with BOS)", b); return CZ_ERR_ARG; }
+        for (size_t i = 0; i < n[b]; ++i) if (ids[b][i] >= V + 256) { cz_set_error("symbol %u >= vocab + 256", ids[b][i]); return CZ_ERR_ARG; }
+        if (ids[b][0] >= V) { cz_set_error("BOS must be a vocabulary token"); return CZ_ERR_ARG; }
+        rowof[b].resize(n[b] - 1);
+        for (size_t i = 0; i + 1 < n[b]; ++i) {
+            if (i == 0 || ids[b][i] < V) toks[b].push_back(ids[b][i]);                       // (:2347: literals are coded, the model is not stepped)
+            rowof[b][i] = (uint32_t)(toks[b].size() - 1);
+        }
+        max_steps = std::max(max_steps, toks[b].size());
+    }
+    if (max_steps == 0) return CZ_OK;
+    const size_t Tb = std::max<size_t>(1, (size_t)g_rw_seq_rows / (size_t)B);
+    const size_t shm = (size_t)(C + 64) * sizeof(float);
+    std::vector<size_t> sym_cur(B, 0);                                                       // next coded symbol of every stream
+    for (size_t t0 = 0; t0 < max_steps; t0 += Tb) {
+        // pack the block: rows of stream b = its steps [t0, min(t0 + Tb, steps_b))
+        std::vector<int> s_row0, s_len, s_stream, row_prev; std::vector<uint32_t> tok;
+        for (int b = 0; b < B; ++b) {
+            if (toks[b].size() <= t0) continue;
+            const size_t len = std::min(Tb, toks[b].size() - t0);
+            s_row0.push_back((int)tok.size()); s_len.push_back((int)len); s_stream.push_back(b);
+            for (size_t t = 0; t < len; ++t) { row_prev.push_back(t == 0 ? -1 - b : (int)tok.size() - 1); tok.push_back(toks[b][t0 + t]); }
+        }
+        const int M = (int)tok.size(), nb = (int)s_stream.size();
+        // coded symbols whose logits row lies in this block
+        std::vector<int> crow; std::vector<uint32_t> csym; struct Dst { int b; size_t i; }; std::vector<Dst> cdst;
+        for (int k = 0; k < nb; ++k) {
+            const int b = s_stream[k];
+            size_t& i = sym_cur[b];
+            while (i + 1 < n[b] && rowof[b][i] < t0 + (size_t)s_len[k]) {
+                crow.push_back(s_row0[k] + (int)(rowof[b][i] - t0)); csym.push_back(ids[b][i + 1]); cdst.push_back({b, i}); ++i;
+            }
+        }
+        const size_t Lr = crow.size();
+        // device copies of the block's index arrays: s_row0 | s_len | s_stream | row_prev | crow, then tok, csym
+        const size_t n_idx = (size_t)3 * nb + M + Lr;
+        CZCHK(m->q_idx.ensure((n_idx + (size_t)M + Lr) * 4 + 64));
+        std::vector<int> hidx; hidx.reserve(n_idx + M + Lr);
+        hidx.insert(hidx.end(), s_row0.begin(), s_row0.end()); hidx.insert(hidx.end(), s_len.begin(), s_len.end()); hidx.insert(hidx.end(), s_stream.begin(), s_stream.end());
+        hidx.insert(hidx.end(), row_prev.begin(), row_prev.end()); hidx.insert(hidx.end(), crow.begin(), crow.end());
+        for (uint32_t t : tok) hidx.push_back((int)t);
+        for (uint32_t t : csym) hidx.push_back((int)t);
+        HIPCHK(hipMemcpyAsync(m->q_idx.p, hidx.data(), hidx.size() * 4, hipMemcpyHostToDevice, st));
+        const int* d_row0 = (const int*)m->q_idx.p; const int* d_len = d_row0 + nb; const int* d_stream = d_len + nb; const int* d_prev = d_stream + nb;
+        const int* d_crow = d_prev + M; const uint32_t* d_tok = (const uint32_t*)(d_crow + Lr); const uint32_t* d_csym = d_tok + M;
+        CZCHK(m->q_x.ensure((size_t)M * C * 4)); CZCHK(m->q_xa.ensure((size_t)M * C * 4)); CZCHK(m->q_mix.ensure((size_t)6 * M * C * 4));
+        CZCHK(m->q_p.ensure((size_t)M * ldp * 4)); CZCHK(m->q_tl.ensure((size_t)M * ptl * 4)); CZCHK(m->q_l2.ensure((size_t)M * 4 * C * 4));
+        CZCHK(m->q_sc.ensure((size_t)M * H * RW_SC * 4)); CZCHK(m->q_vf.ensure((size_t)M * C * 4)); CZCHK(m->q_y.ensure((size_t)M * C * 4));
+        CZCHK(m->q_ffk.ensure((size_t)M * F * 4));
+        float *X = (float*)m->q_x.p, *XA = (float*)m->q_xa.p, *MIX = (float*)m->q_mix.p, *P = (float*)m->q_p.p, *TL = (float*)m->q_tl.p, *L2 = (float*)m->q_l2.p;
+        float *SC = (float*)m->q_sc.p, *VF = (float*)m->q_vf.p, *Y = (float*)m->q_y.p, *FFK = (float*)m->q_ffk.p;
+        const size_t ms = (size_t)M * C;
+        auto gemm = [&](const float* A, int lda, const uint16_t* W, float* Cc, int ldc, const float* R, int N, int K) -> hipError_t {
+            s->prof_begin(M <= 64 ? PK_GEMM_SKINNY : (N % 128 ? PK_GEMM_N64 : PK_GEMM));
+            const hipError_t e = cz_launch_gemm(st, A, lda, W, Cc, ldc, R, ldc, M, N, K, 0);
+            s->prof_end(2.0 * M * (double)N * K, (double)N * K * 2 + (double)M * (N + K) * 4);
+            return e;
+        };
+        s->prof_begin(PK_EMBED); HIPCHK(cz_launch_embed(st, d_tok, m->emb, X, M, C)); s->prof_end(0, (double)M * C * 6);
+        for (int l = 0; l < L; ++l) {
+            const RwLayer& y = m->L[l];
+            float* axp = m->att_x_prev + (size_t)l * Bc * C; float* fxp = m->ffn_x_prev + (size_t)l * Bc * C;
+            float* S = m->att_state + (size_t)l * Bc * H * 64 * 64;
+            s->prof_begin(PK_RWKV);
+            hipLaunchKernelGGL(rw_seq_ln_kernel, dim3(M), dim3(C), shm, st, X, (const int*)nullptr, l == 0 ? y.pre_w : nullptr, y.pre_b, y.ln1_w, y.ln1_b, c.norm_eps, XA);
+            RwMixW mw{{y.x_r, y.x_w, y.x_k, y.x_v, y.x_a, y.x_g}};
+            hipLaunchKernelGGL((rw_seq_mix_kernel<6>), dim3(M), dim3(C), 0, st, XA, d_prev, axp, mw, MIX, ms);
+            hipLaunchKernelGGL(rw_seq_carry_kernel, dim3(nb), dim3(C), 0, st, XA, d_row0, d_len, d_stream, axp);      // state.att_x_prev (:308)
+            HIPCHK(hipGetLastError());
+            s->prof_end(0, (double)M * C * 4 * 10);
+            // projections of the mixed inputs (order r w k v a g): r, k, v, and the LoRA down-projections
+            HIPCHK(gemm(MIX + 0 * ms, C, y.r_n, P + 0, ldp, nullptr, C, C));
+            HIPCHK(gemm(MIX + 2 * ms, C, y.k_n, P + C, ldp, nullptr, C, C));
+            HIPCHK(gemm(MIX + 3 * ms, C, y.v_n, P + 2 * C, ldp, nullptr, C, C));
+            HIPCHK(gemm(MIX + 1 * ms, C, y.w1_n, P + ow, ldp, nullptr, pw, C));
+            HIPCHK(gemm(MIX + 4 * ms, C, y.a1_n, P + oa, ldp, nullptr, pa, C));
+            HIPCHK(gemm(MIX + 5 * ms, C, y.g1_n, P + og, ldp, nullptr, pg, C));
+            if (y.has_v) HIPCHK(gemm(MIX + 3 * ms, C, y.v1_n, P + ov, ldp, nullptr, pv, C));
+            s->prof_begin(PK_RWKV);
+            hipLaunchKernelGGL(rw_seq_lora_act_kernel, dim3(M), dim3(128), 0, st, P, ldp, ow, oa, og, ov, c.decay_rank, c.a_rank, c.gate_rank, y.has_v ? c.v_rank : 0, TL, pw, pa, pg, pv);
+            HIPCHK(hipGetLastError());
+            s->prof_end(0, (double)M * ptl * 8);
+            HIPCHK(gemm(TL, ptl, y.w2_n, L2 + 0, 4 * C, nullptr, C, pw));
+            HIPCHK(gemm(TL + pw, ptl, y.a2_n, L2 + C, 4 * C, nullptr, C, pa));
+            HIPCHK(gemm(TL + pw + pa, ptl, y.g2_n, L2 + 2 * C, 4 * C, nullptr, C, pg));
+            if (y.has_v) HIPCHK(gemm(TL + pw + pa + pg, ptl, y.v2_n, L2 + 3 * C, 4 * C, nullptr, C, pv));
+            s->prof_begin(PK_RWKV);
+            hipLaunchKernelGGL(rw_seq_pre_kernel, dim3(M, H), dim3(64), 0, st, P, ldp, L2, y, l, C, VF, SC);
+            hipLaunchKernelGGL(rw_seq_scan_kernel, dim3(nb, H), dim3(64), 0, st, SC, d_row0, d_len, d_stream, S, Y, C);
+            hipLaunchKernelGGL(rw_seq_post_kernel, dim3(M, H), dim3(64), 0, st, Y, SC, L2, y, C, XA);                    // (XA is free again: the gated output goes there)
+            HIPCHK(hipGetLastError());
+            s->prof_end(0, (double)M * H * RW_SC * 4 * 3 + (double)M * C * 4 * 6);
+            HIPCHK(gemm(XA, C, y.o_n, X, C, X, C, C));                                                                   // x = x + att
+            s->prof_begin(PK_RWKV);
+            hipLaunchKernelGGL(rw_seq_ln_kernel, dim3(M), dim3(C), shm, st, X, (const int*)nullptr, (const uint16_t*)nullptr, (const uint16_t*)nullptr, y.ln2_w, y.ln2_b, c.norm_eps, XA);
+            RwMixW fw{{y.fx_k, nullptr, nullptr, nullptr, nullptr, nullptr}};
+            hipLaunchKernelGGL((rw_seq_mix_kernel<1>), dim3(M), dim3(C), 0, st, XA, d_prev, fxp, fw, MIX, ms);
+            hipLaunchKernelGGL(rw_seq_carry_kernel, dim3(nb), dim3(C), 0, st, XA, d_row0, d_len, d_stream, fxp);
+            HIPCHK(hipGetLastError());
+            s->prof_end(0, (double)M * C * 4 * 5);
+            s->prof_begin(PK_GEMM);
+            HIPCHK(cz_launch_gemm_relusq(st, MIX, C, y.fk_n, FFK, F, M, F, C));
+            s->prof_end(2.0 * M * (double)F * C, (double)F * C * 2 + (double)M * (F + C) * 4);
+            HIPCHK(gemm(FFK, F, y.fv_n, X, C, X, C, F));                                                                 // x = x + ffn
+        }
+        // logits of the coded symbols' rows -> coder intervals (combined_pdf_with_literals + inline quantiser, src/main.rs:2303-2325)
+        CZCHK(s->clo.ensure(Lr * 4 + 16)); CZCHK(s->chi.ensure(Lr * 4 + 16));
+        const size_t LB = std::max<size_t>(1, std::min(s->logit_batch_rows, (size_t)(1ull << 31) / ((size_t)c.vocab * 4)));
+        CZCHK(s->logits.ensure(std::min(LB, std::max<size_t>(Lr, 1)) * (size_t)c.vocab * 4)); CZCHK(m->q_xn.ensure(std::min(LB, std::max<size_t>(Lr, 1)) * (size_t)C * 4));
+        for (size_t r0 = 0; r0 < Lr; r0 += LB) {
+            const int nr = (int)std::min(LB, Lr - r0);
+            s->prof_begin(PK_RWKV);
+            hipLaunchKernelGGL(rw_seq_ln_kernel, dim3(nr), dim3(C), shm, st, X, d_crow + r0, (const uint16_t*)nullptr, (const uint16_t*)nullptr, m->lno_w, m->lno_b, c.norm_eps, (float*)m->q_xn.p);
+            HIPCHK(hipGetLastError());
+            s->prof_end(0, (double)nr * C * 8);
+            s->prof_begin(nr <= 64 ? PK_GEMM_SKINNY : PK_GEMM);
+            HIPCHK(cz_launch_gemm(st, (const float*)m->q_xn.p, C, m->head_n, (float*)s->logits.p, c.vocab, nullptr, 0, nr, c.vocab, C, 0));
+            s->prof_end(2.0 * nr * (double)c.vocab * C, (double)c.vocab * C * 2 + (double)nr * (c.vocab + C) * 4);
+            s->prof_begin(PK_CDF);
+            HIPCHK(cz_launch_cdf_pairs(st, (const float*)s->logits.p, c.vocab, d_csym + r0, (uint32_t*)s->clo.p + r0, (uint32_t*)s->chi.p + r0, nr, c.vocab, 1, s->fallback_dev, s->cdf_scratch));
+            s->prof_end(0, (double)nr * c.vocab * 4);
+        }
+        std::vector<uint32_t> hlo(Lr), hhi(Lr);
+        if (Lr) {
+            HIPCHK(hipMemcpyAsync(hlo.data(), s->clo.p, Lr * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(hhi.data(), s->chi.p, Lr * 4, hipMemcpyDeviceToHost, st));
+        }
+        HIPCHK(hipStreamSynchronize(st));                                   // (the block's host index vectors go out of scope)
+        for (size_t r = 0; r < Lr; ++r) { lo[cdst[r].b][cdst[r].i] = hlo[r]; hi[cdst[r].b][cdst[r].i] = hhi[r]; }
+    }
+    return CZ_OK;
+}
+// every stream of the batch, groups of max_streams one after the other on this session (no lanes: the blocks are whole-device work)
+cz_status cz_rwkv7_encode_seq(cz_session* s, size_t n_streams, const uint32_t* const* ids, const size_t* n, uint32_t* const* lo, uint32_t* const* hi) {
+    const size_t cap = (size_t)s->max_streams;
+    for (size_t g0 = 0; g0 < n_streams; g0 += cap) {
+        const int B = (int)std::min(cap, n_streams - g0);
+        CZCHK(rw_encode_seq_group(s, B, ids + g0, n + g0, lo + g0, hi + g0));
+    }
+    s->index_pos = 0;
     return CZ_OK;
 }
 

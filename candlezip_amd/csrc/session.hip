@@ -34,6 +34,7 @@ extern int g_dec_attn_split_heads;
 extern int g_dec_attn_lds_pad;
 extern int g_dec_wide_rows;
 extern int g_dec_attn_small_grid;
+extern int g_rw_seq_rows;
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t _e = (expr);                                                                        \
@@ -1198,6 +1199,7 @@ extern "C" cz_status cz_encode_tokens_batch(cz_session* s, size_t n_streams, con
     HIPCHK(hipSetDevice(s->device));
     if (s->backend == CZ_BACKEND_RWKV7) {                  // RWKV has no re-prime: encode walks the recurrence in lock-step too, one group per lane
         if (n_streams == 0) return CZ_OK;
+        if (s->rwkv_seq) return cz_rwkv7_encode_seq(s, n_streams, ids, n, out_c_lo, out_c_hi);   // teacher-forced: all tokens of a block through the GEMMs at once
         return run_on_lanes(s, n_streams, [&](cz_session* ls, size_t o, size_t cnt) {
             return cz_rwkv7_encode_group(ls, (int)cnt, ids + o, n + o, out_c_lo + o, out_c_hi + o);
         });
@@ -1491,6 +1493,8 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "wide_mode")) s->wide_mode = (int)value;
     else if (!strcmp(key, "gemm_mid_rows")) g_gemm_mid_rows = (int)value;
     else if (!strcmp(key, "no_last_prune")) s->no_last_prune = (int)value;
+    else if (!strcmp(key, "rwkv_seq")) s->rwkv_seq = (int)value;
+    else if (!strcmp(key, "rwkv_seq_rows")) g_rw_seq_rows = (int)value < 1 ? 1 : (int)value;
     else if (!strcmp(key, "mid_nw")) g_mid_nw = (int)value;
     else if (!strcmp(key, "dec_attn_split_heads")) g_dec_attn_split_heads = (int)value;
     else if (!strcmp(key, "dec_attn_lds_pad")) g_dec_attn_lds_pad = (int)value;              // (before the first decode: the kernels' LDS limit is set once)

@@ -114,7 +114,7 @@ def test_trait_steps_past_the_initial_kv_cache(cz, czo):
     g = cz.Session("smollm", gcfg, seed=11, embed_std=0.05, max_streams=2)
     o = czo.SmolLmSession(ocfg, seed=11, embed_std=0.05)
     rng = np.random.default_rng(9)
-    toks = rng.integers(0, 512, 2400).astype(np.uint32)
+    toks = rng.integers(0, 512, 4200).astype(np.uint32)
     a = g.reprime_with_history_and_get_last_logits_tensor(toks[:2040]); b = o.reprime_logits(toks[:2040])
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     for i in range(2040, 2062):
@@ -125,9 +125,11 @@ def test_trait_steps_past_the_initial_kv_cache(cz, czo):
     with pytest.raises(cz.CandlezipError, match="max_position_embeddings"):
         g.step_logits_tensor(toks[6])
     with pytest.raises(cz.CandlezipError, match="max_position_embeddings"):
-        g.encode_tokens(np.concatenate([[0], toks[:2399]]).astype(np.uint32), 512, 2000)               # 511 + 2000 > 2304
+        g.encode_tokens(np.concatenate([[0], toks[:4100]]).astype(np.uint32), 512, 2000)               # the segment after i = 2000 would run to 511 + 2000 > 2304 positions
     with pytest.raises(cz.CandlezipError, match="max_position_embeddings"):
-        g.decode_tokens(b"\x00" * 64, 2399, 512, 2000, 0)
+        g.decode_tokens(b"\x00" * 64, 4100, 512, 2000, 0)
+    lo, hi = g.encode_tokens(np.concatenate([[0], toks[:2399]]).astype(np.uint32), 512, 2000)          # ... but a file that ends before that is fine, as in the reference
+    assert lo.size == 2399
     g.close(); o.close()
 
 
@@ -157,3 +159,63 @@ def test_encode_between_decode_slices_recaptures_the_step_graph(cz):
     for (lo, hi), (lo2, hi2) in zip(other, chk):
         assert np.array_equal(lo, lo2) and np.array_equal(hi, hi2)
     g.close(); g2.close()
+
+
+@pytest.mark.parametrize("block_rows", [7, 64, 32768])
+def test_rwkv7_sequence_parallel_encode_equals_oracle_and_lockstep_walk(cz, czo, block_rows):
+    """RWKV7 encode, sequence-parallel (all tokens of a time block through the GEMMs at once, only the WKV scan sequential in t;
+    candle_rwkv7/src/models/rwkv7.rs:179-328, 412-430; src/main.rs:2303-2325, 2345-2349) against the oracle's token-by-token walk and against
+    the library's own lock-step walk: coder intervals and payload bytes.  Literals (coded, the model is not stepped), ragged and degenerate
+    streams, more streams than one group, time blocks of 7 / 64 rows (the token shift and the state cross block boundaries) and one block."""
+    g = cz.Session("rwkv7", cz.tiny_rwkv7_config(), seed=9, embed_std=0.05, max_streams=4)
+    o = czo.Rwkv7Session(czo.tiny_rwkv7_config(), seed=9, embed_std=0.05)
+    rng = np.random.default_rng(404)
+    lens = [150, 1, 0, 64, 97, 33, 2]
+    streams = [np.concatenate([[0], rng.integers(0, 512, n)]).astype(np.uint32) for n in lens]
+    streams[0][3] = 512 + 10; streams[0][4] = 512 + 255; streams[0][149] = 512; streams[4][1] = 512 + 7; streams[5][33] = 512 + 99   # literal escapes, first / consecutive / last
+    g.debug_set("rwkv_seq", 1); g.debug_set("rwkv_seq_rows", block_rows)
+    seq = g.encode_tokens_batch(streams)
+    g.debug_set("rwkv_seq", 0)
+    walk = g.encode_tokens_batch(streams)
+    g.debug_set("rwkv_seq", 1); g.debug_set("rwkv_seq_rows", 32768)
+    pays = []
+    for s_, (lo, hi), (lo2, hi2) in zip(streams, seq, walk):
+        ref_p, clo, chi, zw = o.encode_tokens(s_)
+        assert np.array_equal(lo, clo) and np.array_equal(hi, chi), (block_rows, s_.size)
+        assert np.array_equal(lo2, clo) and np.array_equal(hi2, chi)
+        p, zw2 = cz.ac_encode_pairs(lo, hi)
+        assert p == ref_p and zw == zw2
+        pays.append(p)
+    outs = g.decode_tokens_batch(pays, lens)
+    for s_, out in zip(streams, outs):
+        assert np.array_equal(out, s_)
+    assert g.debug_get("cdf_fallback_rows") == 0
+    g.close(); o.close()
+
+
+def test_rwkv7_0b1_shape_sequence_parallel_encode(cz, czo):
+    """the RWKV7-0.1B shape: 24 tokens of two streams against the oracle (every GEMM shape of the sequence-parallel path at its real K / N),
+    then 3 000 tokens x 3 streams: sequence-parallel == lock-step walk, and the round trip"""
+    g = cz.Session("rwkv7", cz.rwkv7_0b1_config(), seed=3, embed_std=0.02, max_streams=3)
+    o = czo.Rwkv7Session(czo.rwkv7_0b1_config(), seed=3, embed_std=0.02)
+    rng = np.random.default_rng(12)
+    small = [np.concatenate([[0], rng.integers(0, 65536, n)]).astype(np.uint32) for n in (14, 10)]
+    small[0][5] = 65536 + 65
+    for s_, (lo, hi) in zip(small, g.encode_tokens_batch(small)):
+        ref_p, clo, chi, _ = o.encode_tokens(s_)
+        assert np.array_equal(lo, clo) and np.array_equal(hi, chi)
+    o.close()
+    big = [np.concatenate([[0], rng.integers(0, 65536 + 256, n)]).astype(np.uint32) for n in (3000, 2500, 700)]
+    for b in big:
+        b[0] = 0
+    seq = g.encode_tokens_batch(big)
+    g.debug_set("rwkv_seq", 0)
+    walk = g.encode_tokens_batch(big)
+    g.debug_set("rwkv_seq", 1)
+    for (lo, hi), (lo2, hi2) in zip(seq, walk):
+        assert np.array_equal(lo, lo2) and np.array_equal(hi, hi2)
+    pays = [cz.ac_encode_pairs(lo, hi)[0] for lo, hi in seq]
+    outs = g.decode_tokens_batch(pays, [b.size - 1 for b in big])
+    for b, out in zip(big, outs):
+        assert np.array_equal(out, b)
+    g.close()
