@@ -55,7 +55,7 @@ FUNCTIONS = {
 }
 
 
-def pmc_traffic(prefix, tokens=1536):
+def pmc_traffic(prefix, tokens=2048):
     """HBM bytes per launch of a kernel function from the committed rocprofv3 --pmc passes (profiles/r*_pmc*_{FETCH,WRITE}_SIZE_pmc.json,
     made by tools/prof_summary.py from separate FETCH_SIZE / WRITE_SIZE runs).  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
     counts 128-B requests of wide coalesced reads at 64 B, so it is doubled (MI355X_MICROARCH.md, "HBM").  The newest file that holds
@@ -322,22 +322,188 @@ def spawn_ranks(n, argv=None, script=None):
     return rc
 
 
+def cpu_baseline_rwkv7(sample_tokens):
+    """the oracle's RWKV7-0.1B walk (one T == 1 forward per token, host CDF with literals, coder), bounded sample"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import czo
+    note("cpu baseline: RWKV7 oracle ...")
+    o = czo.Rwkv7Session(czo.rwkv7_0b1_config(), seed=0x5EED, embed_std=0.02)
+    rng = np.random.default_rng(7)
+    ids = np.concatenate([[0], rng.integers(0, 65536, sample_tokens)]).astype(np.uint32)
+    t0 = time.perf_counter()
+    payload, clo, chi, zw = o.encode_tokens(ids)
+    t1 = time.perf_counter()
+    out = o.decode_tokens(payload, sample_tokens)
+    t2 = time.perf_counter()
+    assert np.array_equal(out, ids)
+    cores = czo.lib().czo_num_threads()
+    o.close()
+    return {"value": round(sample_tokens / (t2 - t0), 2), "unit": "tokens/s", "cores": int(cores), "kind": "port",
+            "sample": f"self-test (compress {t1 - t0:.1f}s + decompress {t2 - t1:.1f}s) of one {sample_tokens}-token stream, RWKV7-0.1B shape, f32, OpenMP oracle",
+            "compress_tokens_per_s": round(sample_tokens / (t1 - t0), 2), "decompress_tokens_per_s": round(sample_tokens / (t2 - t1), 2)}
+
+
+def main_rwkv7(args):
+    """BASELINE configs[3]: `--backend rwkv7` on Canterbury-sized inputs, 1 GPU, recurrent-state kernel path.  One step = the self-test of a fresh
+    batch: `--streams` streams (64 KiB chunks of the corpus) x `--sample-tokens` tokens each — compress (sequence-parallel: every token of a time
+    block through the projections at once, only the WKV scan sequential in t) + the serial coder + decompress (lock-step groups on decode lanes) —
+    round trip verified every step.  RWKV has no re-prime: a stream's state starts at zero, like a file's.  Weights / ids synthetic (no
+    checkpoint, vocabulary or corpus offline): bits/byte is null."""
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("CZ_BENCH_DIST_BACKEND", "nccl")
+        if backend == "gloo":
+            local = local % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    import candlezip_amd as cz
+    cfg = cz.tiny_rwkv7_config() if args.tiny else cz.rwkv7_0b1_config()
+    S, T = args.streams, args.sample_tokens
+    groups = max(1, min(args.lanes, -(-S // args.lane_streams)))
+    per_lane = min(1024, -(-S // groups))
+    sess = cz.Session("rwkv7", cfg, seed=0x5EED, embed_std=0.02, device=local, max_streams=per_lane)
+    sess.debug_set("max_lanes", groups)
+    if args.no_graph:
+        sess.debug_set("no_graph", 1)
+    for kv in args.debug_set:
+        k, v = kv.split("=")
+        sess.debug_set(k, int(v))
+    note(f"rank {rank}/{world}: rwkv7 session open, {S} streams x {T} tokens, {groups} lanes x {per_lane}")
+
+    def batch(step):
+        rng = np.random.default_rng([4000 + rank, step])
+        return [np.concatenate([[0], rng.integers(0, cfg.vocab, T)]).astype(np.uint32) for _ in range(S)]
+
+    te = td = 0.0; nbytes = 0
+
+    def one(step):
+        nonlocal te, td, nbytes
+        streams = batch(step)
+        t0 = time.perf_counter()
+        pairs = sess.encode_tokens_batch(streams)
+        pays = [cz.ac_encode_pairs(lo, hi)[0] for lo, hi in pairs]
+        t1 = time.perf_counter()
+        outs = sess.decode_tokens_batch(pays, [T] * S)
+        t2 = time.perf_counter()
+        for a, b in zip(streams, outs):
+            if not np.array_equal(a, b):
+                raise RuntimeError("self-test round trip mismatch")
+        te += t1 - t0; td += t2 - t1; nbytes += sum(len(p) for p in pays)
+
+    def barrier():
+        sess.synchronize()
+        if dist is not None:
+            dist.barrier()
+            sess.synchronize()
+
+    sess.profile_enable(False)
+    for w in range(args.warmup):
+        one(-1 - w)
+    te = td = 0.0; nbytes = 0
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one(k)
+        note(f"step {k + 1}/{args.steps}: compress {te:.1f}s decompress {td:.1f}s")
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tok = args.steps * S * T
+    # eager per-family pass: one lock-step group alone, every family bracketed by HIP events
+    prof = {}
+    if args.profile_tokens > 0:
+        pt = min(args.profile_tokens, T)
+        rng = np.random.default_rng(99)
+        short = [np.concatenate([[0], rng.integers(0, cfg.vocab, pt)]).astype(np.uint32) for _ in range(min(per_lane, S))]
+        sess.debug_set("no_graph", 1)
+        sess.profile_enable(True)
+        pairs = sess.encode_tokens_batch(short)
+        pays = [cz.ac_encode_pairs(lo, hi)[0] for lo, hi in pairs]
+        outs = sess.decode_tokens_batch(pays, [pt] * len(short))
+        prof = sess.profile_read()
+        sess.profile_enable(False)
+        sess.debug_set("no_graph", 1 if args.no_graph else 0)
+        if not all(np.array_equal(a, b) for a, b in zip(short, outs)):
+            raise RuntimeError("self-test round trip mismatch (profile pass)")
+        note("eager per-family pass done")
+    if dist is not None:
+        import torch
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+        c = torch.tensor([tok], dtype=torch.float64, device=dev); dist.all_reduce(c, op=dist.ReduceOp.SUM); total_tok = float(c.item())
+    else:
+        total_tok = float(tok)
+    if rank == 0:
+        def roof(fam, bound, prefix, kernel):
+            st = prof.get(fam)
+            if not st or not st["total_ms"]:
+                return None
+            ms, n = st["total_ms"], max(st["launches"], 1)
+            if bound == "mfma":
+                ach = st["flops"] / (ms * 1e-3) / 1e12
+                r = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4)}
+            else:
+                ach = st["bytes"] / (ms * 1e-3) / 1e9
+                r = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5)}
+            traffic, tnote = pmc_traffic(prefix, "rwkv7")
+            rp_us, rp_src = rocprof_avg_us(prefix, "rwkv7")
+            r.update({"traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": tnote, "kernel": kernel, "family": fam,
+                      "algorithmic_per_launch": round((st["flops"] if bound == "mfma" else st["bytes"]) / n), "algorithmic_unit": "flop" if bound == "mfma" else "bytes",
+                      "launches": st["launches"], "avg_launch_us": round(1e3 * ms / n, 3), "avg_kernel_us_rocprof": rp_us, "avg_kernel_us_rocprof_source": rp_src,
+                      "total_ms": round(ms, 2), "measured_in": f"eager per-family pass inside bench.py ({min(per_lane, S)} streams x {min(args.profile_tokens, T)} tokens, one lane)"})
+            if rp_us:
+                alg = (st["flops"] if bound == "mfma" else st["bytes"]) / n
+                r["achieved_rocprof"] = round(alg / (rp_us * 1e-6) / (1e12 if bound == "mfma" else 1e9), 3)
+                r["frac_rocprof"] = round(r["achieved_rocprof"] / (FP32_MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS), 4)
+            return r
+        line = {
+            "metric": "tokens/sec, Canterbury-style self-test (compress+decompress), rwkv7",
+            "value": round(total_tok / elapsed, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"--backend rwkv7, Canterbury-sized inputs as 64 KiB chunks: {S} streams x {T} tokens per GPU and step, one step = compress "
+                                   f"(sequence-parallel) + coder + decompress (lock-step) of a fresh batch, RWKV7-0.1B shape ({'tiny test model' if args.tiny else 'C768 L12 H12x64 ffn3072 V65536 (+256 literals)'}), seeded synthetic weights",
+                       "streams_per_gpu": S, "decode_lanes": groups, "streams_per_lane": per_lane, "tokens_per_stream": T, "parallelism": f"files x{world} (no data-path collective)"},
+            "bits_per_byte": None, "bits_per_token_synthetic": round(8.0 * nbytes / max(tok, 1), 3),
+            "steps_verified": args.steps, "ranks_seen": (dist.get_world_size() if dist is not None else 1),
+            "compress_tokens_per_s_rank0": round(tok / te, 1) if te else None, "decompress_tokens_per_s_rank0": round(tok / td, 1) if td else None,
+            "roofline": roof("rwkv7_state", "hbm", "rw_state_kernel", "rw_state_kernel (decode: WKV state update of one token per stream)"),
+            "roofline_scan": roof("rwkv7_scan", "hbm", "rw_seq_scan_kernel", "rw_seq_scan_kernel (encode: WKV scan over a time block, state in registers)"),
+            "roofline_rwkv_gemm_decode": roof("rwkv7_gemm", "mfma", "gemm_bf16w_kernel", "projections of the decode step"),
+            "roofline_mfma_gemm": roof("gemm_bf16w_f32_mfma", "mfma", "gemm_bf16w_kernel<128, 128", "gemm_bf16w_kernel (encode projections, lm_head)"),
+            "families_ms_profile_pass": {k: round(v["total_ms"], 2) for k, v in prof.items()},
+        }
+        if world == 1 and args.cpu_sample > 0 and not args.tiny:
+            line["cpu_baseline"] = cpu_baseline_rwkv7(min(args.cpu_sample, 400))
+        print(json.dumps(line), flush=True)
+    sess.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=17, help="timed steps; 34 windows of 512 tokens are one 64 KiB sample per stream")
+    ap.add_argument("--backend", default="smollm", choices=["smollm", "rwkv7"], help="smollm (default: BASELINE configs[2], the driver's line) or rwkv7 (configs[3])")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps; 34 windows of 512 tokens are one 64 KiB sample per stream")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=1024, help="streams (64 KiB chunks) per GPU, decoded in lock-step (KV cache: 94 MB per stream)")
-    ap.add_argument("--lanes", type=int, default=2, help="concurrent lock-step decode groups per GPU (library decode lanes)")
-    ap.add_argument("--lane-streams", type=int, default=512, help="streams per lock-step group (>= 256: the wide-group decode step)")
-    ap.add_argument("--sample-tokens", type=int, default=17408, help="tokens per stream (a 64 KiB enwik8 sample is ~17.4k SmolLM2 tokens)")
+    ap.add_argument("--streams", type=int, default=None, help="streams (64 KiB chunks) per GPU, decoded in lock-step (KV cache: 94 MB per stream)")
+    ap.add_argument("--lanes", type=int, default=None, help="concurrent lock-step decode groups per GPU (library decode lanes)")
+    ap.add_argument("--lane-streams", type=int, default=None, help="streams per lock-step group (>= 256: the wide-group decode step)")
+    ap.add_argument("--sample-tokens", type=int, default=None, help="tokens per stream (a 64 KiB enwik8 sample is ~17.4k SmolLM2 tokens)")
     ap.add_argument("--window", type=int, default=512, help="tokens per stream and step; a multiple of the re-prime interval, so that no window re-computes another one's history rows")
     ap.add_argument("--overlap", type=int, default=1, help="1 (default): the compress half of a step runs on a forked session WHILE the decompress half runs (+3-4 %: MFMA-bound beside HBM-bound); 0: one after the other, so that the two halves are timed alone")
     ap.add_argument("--no-graph", action="store_true", help="launch the decode step eagerly (one AQL packet per submission: for rocprofv3 --pmc)")
     ap.add_argument("--no-events", action="store_true", help="no HIP-event timing inside the timed region (for rocprofv3 --pmc)")
     ap.add_argument("--step-sync", action="store_true", help="with --no-graph: synchronise after every decode step, so that launches never queue up (rocprofv3 --pmc, DESIGN.md §9)")
     ap.add_argument("--kv-ctx-cap", type=int, default=0, help="tuning: positions per stream in the KV cache (0 = library default 2048)")
-    ap.add_argument("--profile-tokens", type=int, default=2048, help="tokens/stream of the untimed eager per-family profiling pass (0 = skip); its first --profile-skip tokens run with the timers off")
+    ap.add_argument("--profile-tokens", type=int, default=None, help="tokens/stream of the untimed eager per-family profiling pass (0 = skip); its first --profile-skip tokens run with the timers off")
     ap.add_argument("--profile-skip", type=int, default=-1, help="tokens/stream at the start of the profiling pass that are not timed (the ramp-up to the steady-state sawtooth); -1 = one re-prime interval")
     ap.add_argument("--context", type=int, default=512)
     ap.add_argument("--reprime-interval", type=int, default=512)
@@ -347,9 +513,18 @@ def main():
     ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE", help="library tuning knob (cz_debug_set)")
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check only)")
     args = ap.parse_args()
+    # defaults per backend: smollm = 1024 persistent streams x 17 408 tokens in 2 lock-step groups of 512, 17 window steps;
+    # rwkv7 = 512 streams x 4096 tokens per step in 2 groups of 256, 3 steps
+    dflt = {"smollm": dict(steps=17, streams=1024, lanes=2, lane_streams=512, sample_tokens=17408, profile_tokens=2048),
+            "rwkv7": dict(steps=3, streams=512, lanes=2, lane_streams=256, sample_tokens=4096, profile_tokens=512)}[args.backend]
+    for k, v in dflt.items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # no launcher: be one (before any GPU call in this process)
         sys.exit(spawn_ranks(args.gpus))
 
+    if args.backend == "rwkv7":
+        return main_rwkv7(args)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     # One rank needs no torch at all: the product is libcandlezip_hip.so on the system ROCm runtime it links (ldd: /opt/rocm/lib/libamdhip64.so.7).

@@ -319,7 +319,7 @@ class Session:
     # ---- measurement
     KINDS = ["gemm_bf16w_f32_mfma", "gemm_skinny_f32_mfma", "attention_f32_mfma", "rmsnorm", "rope", "swiglu", "embed", "cdf_pairs",
              "decode_symbol", "rwkv7_step", "dec_gemm_plain", "dec_attention", "dec_rmsnorm", "dec_gemm_qkv_rope", "dec_gemm_swiglu",
-             "dec_gemm_lm_head", "gemm_bf16w_f32_mfma_n64"]
+             "dec_gemm_lm_head", "gemm_bf16w_f32_mfma_n64", "rwkv7_state", "rwkv7_prep", "rwkv7_gemm", "rwkv7_scan"]
 
     def profile_enable(self, on=True, only=None):
         """HIP-event timing per kernel family on the library's stream; `only` = list of family names to time"""

@@ -33,6 +33,7 @@ hipError_t cz_launch_gu_interleave(hipStream_t st, const uint16_t* W, uint16_t* 
 hipError_t cz_launch_gemm_swiglu(hipStream_t st, const float* A, int lda, const uint16_t* Wi, float* H, int ldh, int M, int f, int K);
 hipError_t cz_launch_gemm(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R, int ldr,
                           int M, int N, int K, int force_big);
+hipError_t cz_launch_gemm_masked(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, int M, int N, int K, const unsigned char* row_mask);
 hipError_t cz_launch_gemm_relusq(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, int M, int N, int K);
 // mid-M GEMM for one wide lock-step decode group (kernels_gemm_mid.hip); Wk = k2-packed copy of the weights (cz_launch_k2_pack)
 hipError_t cz_launch_k2_pack(hipStream_t st, const uint16_t* W, uint16_t* Wk, size_t N, int K, int rot_heads);   // rot_heads: leading 64-row heads stored pair-wise for the RoPE epilogue

@@ -6,6 +6,7 @@
 #include "../../include/candlezip.h"
 #include "cz_kernels.h"
 
+#define CZ_SYNC_EVERY 64     // decode loops wait for the device every this many tokens (bounds the packets queued behind the host; session.hip)
 #define CZ_DEF_CTX 2048      // positions per stream the KV cache starts with (the reference's default sawtooth peaks at 1023, config 5's at 1535);
                              // a run that needs more (a re-prime interval > 1536) gets a cache sized for it, up to cz_ctx_limit()
 
@@ -16,7 +17,7 @@ struct DevBuf {
     void release();
 };
 
-enum ProfKind { PK_GEMM = 0, PK_GEMM_SKINNY, PK_ATTN, PK_RMSNORM, PK_ROPE, PK_SWIGLU, PK_EMBED, PK_CDF, PK_DECODE, PK_RWKV, PK_DEC_GEMM, PK_DEC_ATTN, PK_DEC_NORM, PK_DEC_GEMM_QKV, PK_DEC_GEMM_GU, PK_DEC_GEMM_HEAD, PK_GEMM_N64, PK_COUNT };
+enum ProfKind { PK_GEMM = 0, PK_GEMM_SKINNY, PK_ATTN, PK_RMSNORM, PK_ROPE, PK_SWIGLU, PK_EMBED, PK_CDF, PK_DECODE, PK_RWKV, PK_DEC_GEMM, PK_DEC_ATTN, PK_DEC_NORM, PK_DEC_GEMM_QKV, PK_DEC_GEMM_GU, PK_DEC_GEMM_HEAD, PK_GEMM_N64, PK_RW_STATE, PK_RW_PREP, PK_RW_GEMM, PK_RW_SCAN, PK_COUNT };
 struct ProfAcc { uint64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
 struct ProfEvt { hipEvent_t e0, e1; int kind; double flops, bytes; };
 
@@ -67,6 +68,7 @@ struct cz_session {
     size_t max_batch_rows = 98304, logit_batch_rows = 8192;
     int force_big_gemm = 0, serial_cdf = 0, decode_v1 = 0, no_graph = 0, fuse_norm = 0, step_sync = 0, dbg_skip = 0, wide_min_streams = 256, wide_mode = 3;
     hipGraph_t dbg_g = nullptr; hipGraphExec_t dbg_ge = nullptr;      // cz_debug_decode_steps
+    int rwkv_wide_min = 256;            // RWKV7 lock-step groups of at least this many streams take the tiled-GEMM step (rw_step_wide); 0 = never
     int rwkv_seq = 1;                   // 1 = RWKV7 encode is sequence-parallel (rw_encode_seq_group); 0 = the lock-step token-by-token walk (cz_rwkv7_encode_group)
     int no_last_prune = 0;              // test knob: 1 = the last layer's tail on every row (llama_body)
     int stream_prio = 0;                // HIP priority of this session's stream and of the decode lanes it makes (cz_debug_set "stream_priority")

@@ -33,7 +33,7 @@ template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restrict__ A, int lda,
                                                          const uint16_t* __restrict__ W, float* __restrict__ C, int ldc,
                                                          const float* __restrict__ R, int ldr, int M, int N, int K,
-                                                         int nbx, int nblocks) {
+                                                         int nbx, int nblocks, const unsigned char* __restrict__ row_mask) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int PA = BM / 32, PB = BN / 32;     // staging passes (256 threads x 8 k-values per pass)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restr
                 const int row = bm * BM + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 float v = R ? tot[i][j][r] + rv[r] : tot[i][j][r];
                 if (EPI == 2) { const float z = tot[i][j][r] > 0.0f ? tot[i][j][r] : 0.0f; v = z * z; }     // RWKV7 channel-mix key: relu(x)^2 (rwkv7.rs:426)
-                if (row < M) C[(size_t)row * ldc + col] = v;
+                if (row < M && (!row_mask || row_mask[row])) C[(size_t)row * ldc + col] = v;       // (row_mask: RWKV literal symbols do not step the model, their logits stay)
             }
         }
 }
@@ -235,11 +235,11 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const float* __restric
 
 template <int BM, int BN, int WM, int WN, int EPI = 0>
 static hipError_t launch_big(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R,
-                             int ldr, int M, int N, int K) {
+                             int ldr, int M, int N, int K, const unsigned char* row_mask = nullptr) {
     const size_t smem = (size_t)(BM + BN) * LDK * sizeof(float);
     auto kern = gemm_bf16w_kernel<BM, BN, WM, WN, EPI>;        // (its LDS limit is raised by cz_gemm_prepare, once per device at session open)
     const int nbx = N / BN, nby = (M + BM - 1) / BM, nblocks = nbx * nby;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, st, A, lda, W, C, ldc, R, ldr, M, N, K, nbx, nblocks);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, st, A, lda, W, C, ldc, R, ldr, M, N, K, nbx, nblocks, row_mask);
     return hipGetLastError();
 }
 
@@ -305,6 +305,14 @@ hipError_t cz_launch_gemm(hipStream_t st, const float* A, int lda, const uint16_
     if (M <= g_gemm_mid_rows && (long)((M + 127) / 128) * (N / 64) < 512) return launch_big<64, 64, 2, 2>(st, A, lda, W, C, ldc, R, ldr, M, N, K);
     if (N % 128 == 0) return launch_big<128, 128, 2, 2>(st, A, lda, W, C, ldc, R, ldr, M, N, K);
     return launch_big<128, 64, 2, 2>(st, A, lda, W, C, ldc, R, ldr, M, N, K);
+}
+// C[M][N] = A . W^T for the rows with row_mask != 0 only (the others keep what C held), tiled kernel, any M
+hipError_t cz_launch_gemm_masked(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, int M, int N, int K, const unsigned char* row_mask) {
+    if (M <= 0) return hipSuccess;
+    if (K % 64 != 0 || N % 64 != 0) return hipErrorInvalidValue;
+    if (M <= g_gemm_mid_rows && (long)((M + 127) / 128) * (N / 64) < 512) return launch_big<64, 64, 2, 2>(st, A, lda, W, C, ldc, nullptr, 0, M, N, K, row_mask);
+    if (N % 128 == 0) return launch_big<128, 128, 2, 2>(st, A, lda, W, C, ldc, nullptr, 0, M, N, K, row_mask);
+    return launch_big<128, 64, 2, 2>(st, A, lda, W, C, ldc, nullptr, 0, M, N, K, row_mask);
 }
 // C[M][N] = relu(A . W^T)^2 on the tiled kernel, any M (the RWKV7 channel-mix key projection of a sequence-parallel encode)
 hipError_t cz_launch_gemm_relusq(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, int M, int N, int K) {

@@ -59,14 +59,19 @@ __device__ __forceinline__ int mid_xcd_remap(int bid, int nblocks) {    // block
 template <int TN, int EPI, int NW, bool PF>
 __global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : 1) void gemm_mid_kernel(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Wk,
                                                            float* __restrict__ C, int ldc, const float* __restrict__ R, int ldr,
-                                                           int M, int N, int K, int nbx, int nblocks, mid_rope_args ra_) {
+                                                           int M, int N, int K, int nbx, int nblocks, int colmaj, mid_rope_args ra_) {
     static_assert(TN * 1024 <= 32 * MID_LDK, "a wave's partial tiles are parked in its own activation tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* As = smem + wave * (32 * MID_LDK);                            // wave-private activation tile [32][MID_LDK]; after the chain: this wave's partial tiles
     int* consumed = reinterpret_cast<int*>(smem + NW * (32 * MID_LDK));  // round up to which wave 0 has taken the partials over
+    // An XCD (blocks b, b + 8, ...: speed only) takes a contiguous range of tiles.  Row-major numbering gives it a few row tiles x ALL column
+    // tiles: its L2 fetches the whole weight panel and 1/8 of the activations; column-major (colmaj) a few column tiles x all row tiles: 1/8 of
+    // the weights, all the activations.  The launcher picks the order that fetches fewer bytes over the eight L2s (gate|up at 512 rows:
+    // 3.5 MB of weights x 8 against 1.2 MB of activations x 8).
     const int sid = mid_xcd_remap(blockIdx.x, nblocks);
-    const int bm = sid / nbx, bn = sid % nbx;
+    const int nby = nblocks / nbx;
+    const int bm = colmaj ? sid % nby : sid / nbx, bn = colmaj ? sid / nby : sid % nbx;
     const int lr = lane & 31, lh = lane >> 5;
     const int nk = K >> 6, rounds = (nk + NW - 1) / NW;
     const int srow = lane >> 3, sg = lane & 7;                           // staging: 8 rows x 8 k-groups per pass, 4 passes
@@ -245,13 +250,17 @@ __global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : 1) void gemm_mi
     }
 }
 
+int g_mid_colmaj = -1;        // tuning knob (cz_debug_set "mid_colmaj"): -1 = by operand sizes, 0 = row-major tile order, 1 = column-major
 template <int TN, int EPI, int NW, bool PF>
 static hipError_t launch_mid_nw(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* C, int ldc, const float* R, int ldr, int M, int N, int K,
                                 mid_rope_args ra) {
     const size_t smem = (size_t)(NW * 32 * MID_LDK + 4) * sizeof(float);
     auto kern = gemm_mid_kernel<TN, EPI, NW, PF>;            // (LDS limit: cz_gemm_mid_prepare, once per device at session open)
     const int nbx = N / (32 * TN), nby = (M + 31) / 32, nblocks = nbx * nby;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NW * 64), smem, st, A, lda, Wk, C, ldc, R, ldr, M, N, K, nbx, nblocks, ra);
+    // bytes fetched over the eight XCD L2s: row-major = 8 x weights + activations, column-major = weights + 8 x activations
+    const double wb = (double)N * K * 2, ab = (double)M * K * 4;
+    const int colmaj = g_mid_colmaj < 0 ? (wb + 8 * ab < 8 * wb + ab ? 1 : 0) : g_mid_colmaj;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NW * 64), smem, st, A, lda, Wk, C, ldc, R, ldr, M, N, K, nbx, nblocks, colmaj, ra);
     return hipGetLastError();
 }
 template <int TN, int EPI, int NW, bool PF>

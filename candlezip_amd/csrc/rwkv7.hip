@@ -110,7 +110,7 @@ __device__ float block_layer_norm(float x, const uint16_t* w, const uint16_t* b,
 
 // time-mix prep (rwkv7.rs:468-471, 193-203): [pre-LN for layer 0,] xa = LN1(x); xx = prev - xa; six token-shift mixes in kq layout
 __global__ void rw_prep_att_kernel(float* __restrict__ X, const RwLayer L, int layer0, float eps, float* __restrict__ x_prev /*[B][C]*/,
-                                   float* __restrict__ MIX /*[6][B][C] kq*/, int B, const unsigned char* __restrict__ mask) {
+                                   float* __restrict__ MIX /*[6][B][C] kq (natural when !out_kq)*/, int B, const unsigned char* __restrict__ mask, int out_kq) {
     extern __shared__ float sh[];
     const int b = blockIdx.x, tid = threadIdx.x, C = blockDim.x;
     float x = X[(size_t)b * C + tid];
@@ -118,45 +118,46 @@ __global__ void rw_prep_att_kernel(float* __restrict__ X, const RwLayer L, int l
     const float xa = block_layer_norm(x, L.ln1_w, L.ln1_b, eps, sh);
     const float xx = x_prev[(size_t)b * C + tid] - xa;
     const uint16_t* mixw[6] = {L.x_r, L.x_w, L.x_k, L.x_v, L.x_a, L.x_g};
-    const int kq = kq_idx(tid);
+    const int kq = out_kq ? kq_idx(tid) : tid;
 #pragma unroll
     for (int j = 0; j < 6; ++j) MIX[((size_t)j * B + b) * C + kq] = xa + xx * cz_bf16_to_f32(mixw[j][tid]);
     if (!mask || mask[b]) x_prev[(size_t)b * C + tid] = xa;                  // state.att_x_prev (:308)
 }
 // channel-mix prep (rwkv7.rs:472-474, 414-425)
 __global__ void rw_prep_ffn_kernel(const float* __restrict__ X, const RwLayer L, float eps, float* __restrict__ x_prev, float* __restrict__ XK /*[B][C] kq*/,
-                                   const unsigned char* __restrict__ mask) {
+                                   const unsigned char* __restrict__ mask, int out_kq) {
     extern __shared__ float sh[];
     const int b = blockIdx.x, tid = threadIdx.x, C = blockDim.x;
     const float x = X[(size_t)b * C + tid];
     const float xf = block_layer_norm(x, L.ln2_w, L.ln2_b, eps, sh);
     const float xx = x_prev[(size_t)b * C + tid] - xf;
-    XK[(size_t)b * C + kq_idx(tid)] = xf + xx * cz_bf16_to_f32(L.fx_k[tid]);
+    XK[(size_t)b * C + (out_kq ? kq_idx(tid) : tid)] = xf + xx * cz_bf16_to_f32(L.fx_k[tid]);
     if (!mask || mask[b]) x_prev[(size_t)b * C + tid] = xf;
 }
 // final LayerNorm -> kq layout (rwkv7.rs:515)
-__global__ void rw_ln_out_kernel(const float* __restrict__ X, const uint16_t* w, const uint16_t* bb, float eps, float* __restrict__ Y) {
+__global__ void rw_ln_out_kernel(const float* __restrict__ X, const uint16_t* w, const uint16_t* bb, float eps, float* __restrict__ Y, int out_kq) {
     extern __shared__ float sh[];
     const int b = blockIdx.x, tid = threadIdx.x, C = blockDim.x;
     const float y = block_layer_norm(X[(size_t)b * C + tid], w, bb, eps, sh);
-    Y[(size_t)b * C + kq_idx(tid)] = y;
+    Y[(size_t)b * C + (out_kq ? kq_idx(tid) : tid)] = y;
 }
 // LoRA hidden activations (rwkv7.rs:211, 229, 235, 244): tanh(w1.), a1., sigmoid(g1.), v1.  -> kq layouts padded to 64
 __global__ void rw_lora_act_kernel(const float* __restrict__ P /*[B][ldp]*/, int ldp, int ow, int oa, int og, int ov, int rw, int ra, int rg, int rv,
-                                   float* __restrict__ TW, float* __restrict__ TA, float* __restrict__ TG, float* __restrict__ TV, int pw, int pa, int pg, int pv) {
+                                   float* __restrict__ TW, float* __restrict__ TA, float* __restrict__ TG, float* __restrict__ TV, int pw, int pa, int pg, int pv, int out_kq) {
     const int b = blockIdx.x, t = threadIdx.x;
     const float* p = P + (size_t)b * ldp;
-    if (t < pw) TW[(size_t)b * pw + kq_idx(t)] = t < rw ? cz_tanhf(p[ow + t]) : 0.0f;
-    if (t < pa) TA[(size_t)b * pa + kq_idx(t)] = t < ra ? p[oa + t] : 0.0f;
-    if (t < pg) TG[(size_t)b * pg + kq_idx(t)] = t < rg ? cz_sigmoidf(p[og + t]) : 0.0f;
-    if (t < pv) TV[(size_t)b * pv + kq_idx(t)] = t < rv ? p[ov + t] : 0.0f;
+    const int o = out_kq ? kq_idx(t) : t;
+    if (t < pw) TW[(size_t)b * pw + o] = t < rw ? cz_tanhf(p[ow + t]) : 0.0f;
+    if (t < pa) TA[(size_t)b * pa + o] = t < ra ? p[oa + t] : 0.0f;
+    if (t < pg) TG[(size_t)b * pg + o] = t < rg ? cz_sigmoidf(p[og + t]) : 0.0f;
+    if (t < pv) TV[(size_t)b * pv + o] = t < rv ? p[ov + t] : 0.0f;
 }
 
 // state kernel: block = (stream, head), 64 lanes = state rows (rwkv7.rs:213-222, 231, 239-266, 289-323, 529-542)
 __global__ __launch_bounds__(64) void rw_state_kernel(const float* __restrict__ P /*[B][ldp]: r | k | v*/, int ldp, const float* __restrict__ L2 /*[B][4][C]: w a g nu*/,
                                                       const RwLayer L, int layer, int C, float* __restrict__ S /*[B][H][64][64]*/,
                                                       float* __restrict__ v_first /*[B][C]*/, float* __restrict__ OUT /*[B][C] kq*/,
-                                                      const unsigned char* __restrict__ mask, int B) {
+                                                      const unsigned char* __restrict__ mask, int B, int out_kq) {
     __shared__ float kk[64], av[64], kv[64], wv[64], rv[64], vv[64], yv[64];
     const int b = blockIdx.x, h = blockIdx.y, i = threadIdx.x, c = h * 64 + i;
     const float* p = P + (size_t)b * ldp;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(64) void rw_state_kernel(const float* __restrict__ 
     const float den = sqrtf(s2 * 0.015625f + (float)64e-5);
     const float gn = cen / den * cz_bf16_to_f32(L.gn_w[c]) + cz_bf16_to_f32(L.gn_b[c]);
     const float ad = al * v;
-    OUT[(size_t)b * C + kq_idx(c)] = (gn + ad) * g;
+    OUT[(size_t)b * C + (out_kq ? kq_idx(c) : c)] = (gn + ad) * g;
 }
 
 __global__ void rw_pick_kernel(const uint32_t* __restrict__ ids, const unsigned long long* __restrict__ off, const unsigned long long* __restrict__ n,
@@ -427,7 +428,7 @@ static cz_status rw_reset(cz_session* s) {                        // State::new 
 }
 
 // one token per stream (tokens in m->tok, step mask in m->mask); logits of unmasked rows -> m->logits
-static cz_status rw_step(cz_session* s, int B) {
+static cz_status rw_step_narrow(cz_session* s, int B) {
     Rwkv7Model* m = s->rwkv; const cz_rwkv7_config& c = m->cfg;
     const int C = c.hidden, F = c.d_ffn, H = C / 64, Bc = m->B;
     const int pw = pad64(c.decay_rank), pa = pad64(c.a_rank), pg = 128, pv = pad64(c.v_rank);
@@ -435,14 +436,19 @@ static cz_status rw_step(cz_session* s, int B) {
     hipStream_t st = s->stream;
     const size_t shm = (size_t)(C + 64) * sizeof(float);
     float *TW = m->lora1a, *TA = TW + (size_t)Bc * 64, *TG = TA + (size_t)Bc * 64, *TV = TG + (size_t)Bc * 128;
-    s->prof_begin(PK_RWKV);
+    // per-family events (eager runs with profiling on): prep = LayerNorm / token shift / LoRA activations, gemm = every projection, state = rw_state_kernel
+    const double st_bytes = (double)B * H * 2.0 * 64 * 64 * 4;                            // the state tile read and written once per (stream, head)
+    s->prof_begin(PK_RW_PREP);
     HIPCHK(cz_launch_embed(st, m->tok, m->emb, m->x, B, C));
     for (int l = 0; l < c.n_layers; ++l) {
         const RwLayer& y = m->L[l];
         float* axp = m->att_x_prev + (size_t)l * Bc * C; float* fxp = m->ffn_x_prev + (size_t)l * Bc * C;
         float* S = m->att_state + (size_t)l * Bc * H * 64 * 64;
-        hipLaunchKernelGGL(rw_prep_att_kernel, dim3(B), dim3(C), shm, st, m->x, y, l == 0 ? 1 : 0, c.norm_eps, axp, m->mix, Bc, m->mask);
+        if (l) s->prof_begin(PK_RW_PREP);
+        hipLaunchKernelGGL(rw_prep_att_kernel, dim3(B), dim3(C), shm, st, m->x, y, l == 0 ? 1 : 0, c.norm_eps, axp, m->mix, Bc, m->mask, 1);
         HIPCHK(hipGetLastError());
+        s->prof_end(0, (double)B * C * 4 * 9);
+        s->prof_begin(PK_RW_GEMM);
         const float* MX = m->mix;                                   // [6][Bc][C]: r w k v a g
         auto mixp = [&](int j) { return MX + (size_t)j * Bc * C; };
         {   // seven projections of the six mixed inputs in one launch: r, k, v and the LoRA down-projections w1, a1, g1 (, v1)
@@ -455,9 +461,13 @@ static cz_status rw_step(cz_session* s, int B) {
             const int K[7] = {C, C, C, C, C, C, C};
             HIPCHK(cz_launch_dec_gemm_group(st, y.has_v ? 7 : 6, A, lda, W, Cc, ldc, N, K, B));
         }
+        s->prof_end(2.0 * B * (double)C * (3 * C + c.decay_rank + c.a_rank + c.gate_rank + (y.has_v ? c.v_rank : 0)), 2.0 * C * (3 * C + pw + pa + pg + pv));
+        s->prof_begin(PK_RW_PREP);
         hipLaunchKernelGGL(rw_lora_act_kernel, dim3(B), dim3(128), 0, st, m->proj, ldp, ow, oa, og, ov, c.decay_rank, c.a_rank, c.gate_rank, y.has_v ? c.v_rank : 0,
-                           TW, TA, TG, TV, pw, pa, pg, pv);
+                           TW, TA, TG, TV, pw, pa, pg, pv, 1);
         HIPCHK(hipGetLastError());
+        s->prof_end(0, (double)B * (pw + pa + pg + pv) * 8);
+        s->prof_begin(PK_RW_GEMM);
         float* L2 = m->lora2;                                        // [Bc][4][C]: w_lora, a_lin, g, nu_lin
         {   // the LoRA up-projections in one launch
             const float* A[4] = {TW, TA, TG, TV};
@@ -469,19 +479,105 @@ static cz_status rw_step(cz_session* s, int B) {
             const int K[4] = {pw, pa, pg, pv};
             HIPCHK(cz_launch_dec_gemm_group(st, y.has_v ? 4 : 3, A, lda, W, Cc, ldc, N, K, B));
         }
-        hipLaunchKernelGGL(rw_state_kernel, dim3(B, H), dim3(64), 0, st, m->proj, ldp, L2, y, l, C, S, m->v_first, m->att, m->mask, Bc);
+        s->prof_end(2.0 * B * (double)C * (pw + pa + pg + (y.has_v ? pv : 0)), 2.0 * C * (pw + pa + pg + pv));
+        s->prof_begin(PK_RW_STATE);
+        hipLaunchKernelGGL(rw_state_kernel, dim3(B, H), dim3(64), 0, st, m->proj, ldp, L2, y, l, C, S, m->v_first, m->att, m->mask, Bc, 1);
         HIPCHK(hipGetLastError());
+        s->prof_end(0, st_bytes);
+        s->prof_begin(PK_RW_GEMM);
         HIPCHK(cz_launch_dec_gemm_plain(st, m->att, C, y.o, m->x, C, m->x, B, C, C, nullptr, 0.0f));          // x = x + att
-        hipLaunchKernelGGL(rw_prep_ffn_kernel, dim3(B), dim3(C), shm, st, m->x, y, c.norm_eps, fxp, m->xn, m->mask);
+        s->prof_end(2.0 * B * (double)C * C, 2.0 * C * C);
+        s->prof_begin(PK_RW_PREP);
+        hipLaunchKernelGGL(rw_prep_ffn_kernel, dim3(B), dim3(C), shm, st, m->x, y, c.norm_eps, fxp, m->xn, m->mask, 1);
         HIPCHK(hipGetLastError());
+        s->prof_end(0, (double)B * C * 4 * 4);
+        s->prof_begin(PK_RW_GEMM);
         HIPCHK(cz_launch_dec_gemm_relusq(st, m->xn, C, y.fk, m->ffk, F, B, F, C));
         HIPCHK(cz_launch_dec_gemm_plain(st, m->ffk, F, y.fv, m->x, C, m->x, B, C, F, nullptr, 0.0f));          // x = x + ffn
+        s->prof_end(4.0 * B * (double)C * F, 4.0 * C * F);
     }
-    hipLaunchKernelGGL(rw_ln_out_kernel, dim3(B), dim3(C), shm, st, m->x, m->lno_w, m->lno_b, c.norm_eps, m->xn);
+    s->prof_begin(PK_RW_PREP);
+    hipLaunchKernelGGL(rw_ln_out_kernel, dim3(B), dim3(C), shm, st, m->x, m->lno_w, m->lno_b, c.norm_eps, m->xn, 1);
     HIPCHK(hipGetLastError());
+    s->prof_end(0, (double)B * C * 8);
+    s->prof_begin(PK_DEC_GEMM_HEAD);
     HIPCHK(cz_launch_dec_gemm_masked(st, m->xn, C, m->head, m->logits, c.vocab, nullptr, B, c.vocab, C, m->mask));
-    s->prof_end(2.0 * B * 191e6, 191e6 * 2 + (double)B * 2.36e6 * 2);
+    s->prof_end(2.0 * B * (double)c.vocab * C, 2.0 * c.vocab * C + (double)B * c.vocab * 4);
     return CZ_OK;
+}
+
+// The same step for ONE WIDE lock-step group (B >= rwkv_wide_min streams): natural-layout activations and the LDS-tiled MFMA GEMM for
+// every projection instead of dec_gemm_kernel's 16-row blocks (which re-read the activations once per 32 output columns); the LoRA
+// activations share one [B][320] row so that the four up-projections read slices of it.  Same canonical arithmetic, same bits.
+static cz_status rw_step_wide(cz_session* s, int B) {
+    Rwkv7Model* m = s->rwkv; const cz_rwkv7_config& c = m->cfg;
+    const int C = c.hidden, F = c.d_ffn, H = C / 64, Bc = m->B;
+    const int pw = pad64(c.decay_rank), pa = pad64(c.a_rank), pg = 128, pv = pad64(c.v_rank);
+    const int ow = 3 * C, oa = ow + pw, og = oa + pa, ov = og + pg, ldp = ov + pv;
+    hipStream_t st = s->stream;
+    const size_t shm = (size_t)(C + 64) * sizeof(float);
+    float *TW = m->lora1a, *TA = TW + (size_t)Bc * 64, *TG = TA + (size_t)Bc * 64, *TV = TG + (size_t)Bc * 128;
+    auto gemm = [&](const float* A, int lda, const uint16_t* W, float* Cc, int ldc, const float* R, int N, int K) -> hipError_t {
+        s->prof_begin(PK_RW_GEMM);
+        const hipError_t e = cz_launch_gemm(st, A, lda, W, Cc, ldc, R, ldc, B, N, K, B > 64 ? 1 : 0);
+        s->prof_end(2.0 * B * (double)N * K, 2.0 * N * K + (double)B * (N + K) * 4);
+        return e;
+    };
+    const double st_bytes = (double)B * H * 2.0 * 64 * 64 * 4;
+    s->prof_begin(PK_RW_PREP);
+    HIPCHK(cz_launch_embed(st, m->tok, m->emb, m->x, B, C));
+    for (int l = 0; l < c.n_layers; ++l) {
+        const RwLayer& y = m->L[l];
+        float* axp = m->att_x_prev + (size_t)l * Bc * C; float* fxp = m->ffn_x_prev + (size_t)l * Bc * C;
+        float* S = m->att_state + (size_t)l * Bc * H * 64 * 64;
+        if (l) s->prof_begin(PK_RW_PREP);
+        hipLaunchKernelGGL(rw_prep_att_kernel, dim3(B), dim3(C), shm, st, m->x, y, l == 0 ? 1 : 0, c.norm_eps, axp, m->mix, Bc, m->mask, 0);
+        HIPCHK(hipGetLastError());
+        s->prof_end(0, (double)B * C * 4 * 9);
+        auto mixp = [&](int j) { return m->mix + (size_t)j * Bc * C; };                     // [6][Bc][C]: r w k v a g
+        HIPCHK(gemm(mixp(0), C, y.r_n, m->proj + 0, ldp, nullptr, C, C));
+        HIPCHK(gemm(mixp(2), C, y.k_n, m->proj + C, ldp, nullptr, C, C));
+        HIPCHK(gemm(mixp(3), C, y.v_n, m->proj + 2 * C, ldp, nullptr, C, C));
+        HIPCHK(gemm(mixp(1), C, y.w1_n, m->proj + ow, ldp, nullptr, pw, C));
+        HIPCHK(gemm(mixp(4), C, y.a1_n, m->proj + oa, ldp, nullptr, pa, C));
+        HIPCHK(gemm(mixp(5), C, y.g1_n, m->proj + og, ldp, nullptr, pg, C));
+        if (y.has_v) HIPCHK(gemm(mixp(3), C, y.v1_n, m->proj + ov, ldp, nullptr, pv, C));
+        s->prof_begin(PK_RW_PREP);
+        hipLaunchKernelGGL(rw_lora_act_kernel, dim3(B), dim3(128), 0, st, m->proj, ldp, ow, oa, og, ov, c.decay_rank, c.a_rank, c.gate_rank, y.has_v ? c.v_rank : 0,
+                           TW, TA, TG, TV, pw, pa, pg, pv, 0);
+        HIPCHK(hipGetLastError());
+        s->prof_end(0, (double)B * (pw + pa + pg + pv) * 8);
+        float* L2 = m->lora2;                                                              // [Bc][4][C]: w_lora, a_lin, g, nu_lin
+        HIPCHK(gemm(TW, pw, y.w2_n, L2 + 0, 4 * C, nullptr, C, pw));
+        HIPCHK(gemm(TA, pa, y.a2_n, L2 + C, 4 * C, nullptr, C, pa));
+        HIPCHK(gemm(TG, pg, y.g2_n, L2 + 2 * C, 4 * C, nullptr, C, pg));
+        if (y.has_v) HIPCHK(gemm(TV, pv, y.v2_n, L2 + 3 * C, 4 * C, nullptr, C, pv));
+        s->prof_begin(PK_RW_STATE);
+        hipLaunchKernelGGL(rw_state_kernel, dim3(B, H), dim3(64), 0, st, m->proj, ldp, L2, y, l, C, S, m->v_first, m->att, m->mask, Bc, 0);
+        HIPCHK(hipGetLastError());
+        s->prof_end(0, st_bytes);
+        HIPCHK(gemm(m->att, C, y.o_n, m->x, C, m->x, C, C));                               // x = x + att
+        s->prof_begin(PK_RW_PREP);
+        hipLaunchKernelGGL(rw_prep_ffn_kernel, dim3(B), dim3(C), shm, st, m->x, y, c.norm_eps, fxp, m->xn, m->mask, 0);
+        HIPCHK(hipGetLastError());
+        s->prof_end(0, (double)B * C * 4 * 4);
+        s->prof_begin(PK_RW_GEMM);
+        HIPCHK(cz_launch_gemm_relusq(st, m->xn, C, y.fk_n, m->ffk, F, B, F, C));
+        s->prof_end(2.0 * B * (double)C * F, 2.0 * C * F + (double)B * (C + F) * 4);
+        HIPCHK(gemm(m->ffk, F, y.fv_n, m->x, C, m->x, C, F));                              // x = x + ffn
+    }
+    s->prof_begin(PK_RW_PREP);
+    hipLaunchKernelGGL(rw_ln_out_kernel, dim3(B), dim3(C), shm, st, m->x, m->lno_w, m->lno_b, c.norm_eps, m->xn, 0);
+    HIPCHK(hipGetLastError());
+    s->prof_end(0, (double)B * C * 8);
+    s->prof_begin(PK_DEC_GEMM_HEAD);
+    HIPCHK(cz_launch_gemm_masked(st, m->xn, C, m->head_n, m->logits, c.vocab, B, c.vocab, C, m->mask));
+    s->prof_end(2.0 * B * (double)c.vocab * C, 2.0 * c.vocab * C + (double)B * c.vocab * 4);
+    return CZ_OK;
+}
+static cz_status rw_step(cz_session* s, int B) {
+    if (s->rwkv_wide_min > 0 && B >= s->rwkv_wide_min) return rw_step_wide(s, B);
+    return rw_step_narrow(s, B);
 }
 
 // ------------------------------------------------------------------ session trait (src/models.rs:147-180)
@@ -607,6 +703,7 @@ cz_status cz_rwkv7_encode_group(cz_session* s, int B, const uint32_t* const* ids
         for (size_t i = 0; i + 1 < maxn; ++i) {
             if (use_graph) HIPCHK(hipGraphLaunch(m->genc.e, s->stream));
             else CZCHK(iteration((unsigned long long)i, nullptr));
+            if ((i % CZ_SYNC_EVERY) == CZ_SYNC_EVERY - 1) HIPCHK(hipStreamSynchronize(s->stream));
         }
         std::vector<uint32_t> hlo(npairs), hhi(npairs);
         if (npairs) {
@@ -858,7 +955,7 @@ static cz_status rw_encode_seq_group(cz_session* s, int B, const uint32_t* const
             const RwLayer& y = m->L[l];
             float* axp = m->att_x_prev + (size_t)l * Bc * C; float* fxp = m->ffn_x_prev + (size_t)l * Bc * C;
             float* S = m->att_state + (size_t)l * Bc * H * 64 * 64;
-            s->prof_begin(PK_RWKV);
+            s->prof_begin(PK_RW_PREP);
             hipLaunchKernelGGL(rw_seq_ln_kernel, dim3(M), dim3(C), shm, st, X, (const int*)nullptr, l == 0 ? y.pre_w : nullptr, y.pre_b, y.ln1_w, y.ln1_b, c.norm_eps, XA);
             RwMixW mw{{y.x_r, y.x_w, y.x_k, y.x_v, y.x_a, y.x_g}};
             hipLaunchKernelGGL((rw_seq_mix_kernel<6>), dim3(M), dim3(C), 0, st, XA, d_prev, axp, mw, MIX, ms);
@@ -873,7 +970,7 @@ static cz_status rw_encode_seq_group(cz_session* s, int B, const uint32_t* const
             HIPCHK(gemm(MIX + 4 * ms, C, y.a1_n, P + oa, ldp, nullptr, pa, C));
             HIPCHK(gemm(MIX + 5 * ms, C, y.g1_n, P + og, ldp, nullptr, pg, C));
             if (y.has_v) HIPCHK(gemm(MIX + 3 * ms, C, y.v1_n, P + ov, ldp, nullptr, pv, C));
-            s->prof_begin(PK_RWKV);
+            s->prof_begin(PK_RW_PREP);
             hipLaunchKernelGGL(rw_seq_lora_act_kernel, dim3(M), dim3(128), 0, st, P, ldp, ow, oa, og, ov, c.decay_rank, c.a_rank, c.gate_rank, y.has_v ? c.v_rank : 0, TL, pw, pa, pg, pv);
             HIPCHK(hipGetLastError());
             s->prof_end(0, (double)M * ptl * 8);
@@ -881,14 +978,20 @@ static cz_status rw_encode_seq_group(cz_session* s, int B, const uint32_t* const
             HIPCHK(gemm(TL + pw, ptl, y.a2_n, L2 + C, 4 * C, nullptr, C, pa));
             HIPCHK(gemm(TL + pw + pa, ptl, y.g2_n, L2 + 2 * C, 4 * C, nullptr, C, pg));
             if (y.has_v) HIPCHK(gemm(TL + pw + pa + pg, ptl, y.v2_n, L2 + 3 * C, 4 * C, nullptr, C, pv));
-            s->prof_begin(PK_RWKV);
+            s->prof_begin(PK_RW_PREP);
             hipLaunchKernelGGL(rw_seq_pre_kernel, dim3(M, H), dim3(64), 0, st, P, ldp, L2, y, l, C, VF, SC);
+            HIPCHK(hipGetLastError());
+            s->prof_end(0, (double)M * H * RW_SC * 4 + (double)M * C * 4 * 8);
+            s->prof_begin(PK_RW_SCAN);
             hipLaunchKernelGGL(rw_seq_scan_kernel, dim3(nb, H), dim3(64), 0, st, SC, d_row0, d_len, d_stream, S, Y, C);
+            HIPCHK(hipGetLastError());
+            s->prof_end(0, (double)M * H * RW_SC * 4 + (double)M * C * 4 + (double)nb * H * 2.0 * 64 * 64 * 4);
+            s->prof_begin(PK_RW_PREP);
             hipLaunchKernelGGL(rw_seq_post_kernel, dim3(M, H), dim3(64), 0, st, Y, SC, L2, y, C, XA);                    // (XA is free again: the gated output goes there)
             HIPCHK(hipGetLastError());
-            s->prof_end(0, (double)M * H * RW_SC * 4 * 3 + (double)M * C * 4 * 6);
+            s->prof_end(0, (double)M * H * 3 * 64 * 4 + (double)M * C * 4 * 3);
             HIPCHK(gemm(XA, C, y.o_n, X, C, X, C, C));                                                                   // x = x + att
-            s->prof_begin(PK_RWKV);
+            s->prof_begin(PK_RW_PREP);
             hipLaunchKernelGGL(rw_seq_ln_kernel, dim3(M), dim3(C), shm, st, X, (const int*)nullptr, (const uint16_t*)nullptr, (const uint16_t*)nullptr, y.ln2_w, y.ln2_b, c.norm_eps, XA);
             RwMixW fw{{y.fx_k, nullptr, nullptr, nullptr, nullptr, nullptr}};
             hipLaunchKernelGGL((rw_seq_mix_kernel<1>), dim3(M), dim3(C), 0, st, XA, d_prev, fxp, fw, MIX, ms);
@@ -906,7 +1009,7 @@ static cz_status rw_encode_seq_group(cz_session* s, int B, const uint32_t* const
         CZCHK(s->logits.ensure(std::min(LB, std::max<size_t>(Lr, 1)) * (size_t)c.vocab * 4)); CZCHK(m->q_xn.ensure(std::min(LB, std::max<size_t>(Lr, 1)) * (size_t)C * 4));
         for (size_t r0 = 0; r0 < Lr; r0 += LB) {
             const int nr = (int)std::min(LB, Lr - r0);
-            s->prof_begin(PK_RWKV);
+            s->prof_begin(PK_RW_PREP);
             hipLaunchKernelGGL(rw_seq_ln_kernel, dim3(nr), dim3(C), shm, st, X, d_crow + r0, (const uint16_t*)nullptr, (const uint16_t*)nullptr, m->lno_w, m->lno_b, c.norm_eps, (float*)m->q_xn.p);
             HIPCHK(hipGetLastError());
             s->prof_end(0, (double)nr * C * 8);
@@ -975,6 +1078,7 @@ cz_status cz_rwkv7_decode_advance(cz_session* s, size_t n) {
     for (size_t i = run.i; i < stop; ++i) {
         if (run.use_graph) HIPCHK(hipGraphLaunch(m->gdec.e, s->stream));
         else CZCHK(rw_decode_iteration(s, run.B, (unsigned long long)i, nullptr, i + 1 < run.max_tc));
+        if (((i - run.i) % CZ_SYNC_EVERY) == CZ_SYNC_EVERY - 1) HIPCHK(hipStreamSynchronize(s->stream));   // (bounded queue depth: session.hip, decode_llama_advance)
     }
     run.i = stop;
     HIPCHK(hipStreamSynchronize(s->stream));

@@ -30,6 +30,7 @@ extern int g_dec_mt_max;
 extern int g_dec_norm_mfma;
 extern int g_gemm_mid_rows;
 extern int g_mid_nw;
+extern int g_mid_colmaj;
 extern int g_dec_attn_split_heads;
 extern int g_dec_attn_lds_pad;
 extern int g_dec_wide_rows;
@@ -111,7 +112,8 @@ void cz_session::prof_drain() {
 }
 static const char* kProfNames[PK_COUNT] = {"gemm_bf16w_f32_mfma", "gemm_skinny_f32_mfma", "attention_f32_mfma", "rmsnorm", "rope",
                                            "swiglu", "embed", "cdf_pairs", "decode_symbol", "rwkv7_step", "dec_gemm_plain", "dec_attention", "dec_rmsnorm",
-                                           "dec_gemm_qkv_rope", "dec_gemm_swiglu", "dec_gemm_lm_head", "gemm_bf16w_f32_mfma_n64"};
+                                           "dec_gemm_qkv_rope", "dec_gemm_swiglu", "dec_gemm_lm_head", "gemm_bf16w_f32_mfma_n64",
+                                           "rwkv7_state", "rwkv7_prep", "rwkv7_gemm", "rwkv7_scan"};
 
 // ------------------------------------------------------------------ model construction
 static cz_status synth(cz_session* s, uint16_t* dst, const char* name, size_t numel, float stdv, float mean) {
@@ -1028,6 +1030,11 @@ static cz_status decode_llama_advance(cz_session* s, size_t n) {
             }
             if (s->step_sync) HIPCHK(hipStreamSynchronize(s->stream));    // never more than one step of launches queued (profiler runs)
         }
+        // Bound what is queued behind the host: a token is ~160 kernel packets, and thousands of tokens enqueued without a host
+        // synchronisation let the AQL ring back up when something serialises the dispatches — rocprofv3's counter collection does, and its
+        // write-interceptor then runs past the ring's end (SIGSEGV in librocprofiler-sdk).  One wait every CZ_SYNC_EVERY tokens
+        // (<= ~10 k packets in flight, far below the ring) costs one launch latency per ~100 ms of work.
+        if (((i - run.i) % CZ_SYNC_EVERY) == CZ_SYNC_EVERY - 1) HIPCHK(hipStreamSynchronize(s->stream));
         index_pos += 1;
     }
     run.i = stop;
@@ -1162,7 +1169,7 @@ static cz_status make_lane(cz_session* p, cz_session** out) {
 }
 static void lane_inherit(const cz_session* s, cz_session* ls) {   // a lane runs with its parent's knobs
     ls->kv_ctx_cap = s->kv_ctx_cap; ls->serial_cdf = s->serial_cdf; ls->decode_v1 = s->decode_v1; ls->no_graph = s->no_graph; ls->force_big_gemm = s->force_big_gemm;
-    ls->max_batch_rows = s->max_batch_rows; ls->logit_batch_rows = s->logit_batch_rows; ls->step_sync = s->step_sync; ls->fuse_norm = s->fuse_norm; ls->wide_min_streams = s->wide_min_streams; ls->wide_mode = s->wide_mode; ls->dbg_skip = s->dbg_skip; ls->no_last_prune = s->no_last_prune;
+    ls->max_batch_rows = s->max_batch_rows; ls->logit_batch_rows = s->logit_batch_rows; ls->step_sync = s->step_sync; ls->fuse_norm = s->fuse_norm; ls->wide_min_streams = s->wide_min_streams; ls->wide_mode = s->wide_mode; ls->dbg_skip = s->dbg_skip; ls->no_last_prune = s->no_last_prune; ls->rwkv_seq = s->rwkv_seq; ls->rwkv_wide_min = s->rwkv_wide_min;
 }
 // run `n_streams` streams as groups of <= max_streams on up to max_lanes lanes; group(ls, off, count) processes streams [off, off + count)
 template <class GroupFn>
@@ -1494,8 +1501,10 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "gemm_mid_rows")) g_gemm_mid_rows = (int)value;
     else if (!strcmp(key, "no_last_prune")) s->no_last_prune = (int)value;
     else if (!strcmp(key, "rwkv_seq")) s->rwkv_seq = (int)value;
+    else if (!strcmp(key, "rwkv_wide_min")) s->rwkv_wide_min = (int)value;
     else if (!strcmp(key, "rwkv_seq_rows")) g_rw_seq_rows = (int)value < 1 ? 1 : (int)value;
     else if (!strcmp(key, "mid_nw")) g_mid_nw = (int)value;
+    else if (!strcmp(key, "mid_colmaj")) g_mid_colmaj = (int)value;
     else if (!strcmp(key, "dec_attn_split_heads")) g_dec_attn_split_heads = (int)value;
     else if (!strcmp(key, "dec_attn_lds_pad")) g_dec_attn_lds_pad = (int)value;              // (before the first decode: the kernels' LDS limit is set once)
     else if (!strcmp(key, "dec_wide_rows")) g_dec_wide_rows = (int)value;

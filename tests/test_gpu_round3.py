@@ -219,3 +219,37 @@ def test_rwkv7_0b1_shape_sequence_parallel_encode(cz, czo):
     for b, out in zip(big, outs):
         assert np.array_equal(out, b)
     g.close()
+
+
+@pytest.mark.parametrize("shape", ["tiny", "0b1"])
+def test_rwkv7_wide_group_step_is_bitexact(cz, czo, shape):
+    """the RWKV7 lock-step step of a WIDE group (natural-layout activations, every projection on the LDS-tiled MFMA GEMM, the lm_head masked
+    for streams whose symbol was a literal) against the oracle: trait-step logits, the lock-step encode walk, decode with literals, graph and eager"""
+    if shape == "tiny":
+        gcfg, ocfg, V, n_tok, seed, std = cz.tiny_rwkv7_config(), czo.tiny_rwkv7_config(), 512, 130, 9, 0.05
+    else:
+        gcfg, ocfg, V, n_tok, seed, std = cz.rwkv7_0b1_config(), czo.rwkv7_0b1_config(), 65536, 10, 3, 0.02
+    g = cz.Session("rwkv7", gcfg, seed=seed, embed_std=std, max_streams=5)
+    o = czo.Rwkv7Session(ocfg, seed=seed, embed_std=std)
+    g.debug_set("rwkv_wide_min", 1); g.debug_set("rwkv_seq", 0)
+    rng = np.random.default_rng(8)
+    toks = rng.integers(0, V, 12).astype(np.uint32)
+    o.reset()
+    a = g.reprime_with_history_and_get_last_logits_tensor(toks[:1]); b = o.step_logits(toks[0])
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for t in toks[1:6]:
+        a = g.step_logits_tensor(t); b = o.step_logits(t)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    lens = [n_tok, n_tok // 2, 1, 0, n_tok - 3]
+    streams = [np.concatenate([[0], rng.integers(0, V, n)]).astype(np.uint32) for n in lens]
+    streams[0][2] = V + 65; streams[0][3] = V + 1; streams[4][n_tok - 4] = V + 200
+    pays = []
+    for s_, (lo, hi) in zip(streams, g.encode_tokens_batch(streams)):
+        ref_p, clo, chi, zw = o.encode_tokens(s_)
+        assert np.array_equal(lo, clo) and np.array_equal(hi, chi)
+        pays.append(ref_p)
+    for no_graph in (0, 1):
+        g.debug_set("no_graph", no_graph)
+        for s_, out in zip(streams, g.decode_tokens_batch(pays, lens)):
+            assert np.array_equal(out, s_), no_graph
+    g.close(); o.close()
