@@ -378,7 +378,7 @@ def main_rwkv7(args):
     note(f"rank {rank}/{world}: rwkv7 session open, {S} streams x {T} tokens, {groups} lanes x {per_lane}")
 
     def batch(step):
-        rng = np.random.default_rng([4000 + rank, step])
+        rng = np.random.default_rng([4000 + rank, step + 1000])
         return [np.concatenate([[0], rng.integers(0, cfg.vocab, T)]).astype(np.uint32) for _ in range(S)]
 
     te = td = 0.0; nbytes = 0
