@@ -38,6 +38,9 @@ hipError_t cz_launch_gemm_relusq(hipStream_t st, const float* A, int lda, const 
 // mid-M GEMM for one wide lock-step decode group (kernels_gemm_mid.hip); Wk = k2-packed copy of the weights (cz_launch_k2_pack)
 hipError_t cz_launch_k2_pack(hipStream_t st, const uint16_t* W, uint16_t* Wk, size_t N, int K, int rot_heads);   // rot_heads: leading 64-row heads stored pair-wise for the RoPE epilogue
 hipError_t cz_launch_gemm_mid(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* C, int ldc, const float* R, int ldr, int M, int N, int K);
+hipError_t cz_launch_gemm_mid_relusq(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* C, int ldc, int M, int N, int K);
+hipError_t cz_launch_gemm_mid_group(hipStream_t st, int nprob, const float* const* A, const int* lda, const uint16_t* const* Wk, float* const* C, const int* ldc,
+                                    const int* N, const int* K, int M);
 hipError_t cz_launch_gemm_mid_qkv(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* Q, int ldq, int M, int K, int n_heads, int n_kv,
                                   const cz_rope_desc* descs, size_t kv_off, const int* pos_dev, const float* cs, const float* sn);
 hipError_t cz_launch_gemm_mid_swiglu(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* H, int ldh, int M, int f, int K);

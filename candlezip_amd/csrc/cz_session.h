@@ -68,6 +68,7 @@ struct cz_session {
     size_t max_batch_rows = 98304, logit_batch_rows = 8192;
     int force_big_gemm = 0, serial_cdf = 0, decode_v1 = 0, no_graph = 0, fuse_norm = 0, step_sync = 0, dbg_skip = 0, wide_min_streams = 256, wide_mode = 3;
     hipGraph_t dbg_g = nullptr; hipGraphExec_t dbg_ge = nullptr;      // cz_debug_decode_steps
+    int rwkv_wide_mode = 1;             // rw_step_wide's projections: 1 = gemm_mid_kernel (grouped launches), 0 = the tiled big-M kernel
     int rwkv_wide_min = 256;            // RWKV7 lock-step groups of at least this many streams take the tiled-GEMM step (rw_step_wide); 0 = never
     int rwkv_seq = 1;                   // 1 = RWKV7 encode is sequence-parallel (rw_encode_seq_group); 0 = the lock-step token-by-token walk (cz_rwkv7_encode_group)
     int no_last_prune = 0;              // test knob: 1 = the last layer's tail on every row (llama_body)

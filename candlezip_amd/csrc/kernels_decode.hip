@@ -113,6 +113,53 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
         }
     }
     const int K = a.K, nch = K >> 6;
+    // A narrow group's kernel is a chain of dependent memory round trips (HBM-cold weights ~2 us each), not of arithmetic: everything that
+    // does not depend on a result is requested HERE, before the norm phase and its barrier — the first round's weight slab, the plain A
+    // operand (PFA: where its registers are affordable), the step position and the rotation's cos / sin (epilogue) — so that the chain is one
+    // round trip long instead of three or four.  (Loads only: the arithmetic and its order are untouched.)
+    unsigned w0[NP][8], w1[NP][8];
+    auto load_w = [&](int c, unsigned (&d0)[NP][8], unsigned (&d1)[NP][8]) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const uint4* b0p = reinterpret_cast<const uint4*>(a.Wd + (size_t)(n0[p] + li) * K + c * 64 + lg * 16);
+            const uint4* b1p = reinterpret_cast<const uint4*>(a.Wd + (size_t)(n1[p] + li) * K + c * 64 + lg * 16);
+            const uint4 b0a = b0p[0], b0b = b0p[1], b1a = b1p[0], b1b = b1p[1];
+            d0[p][0] = b0a.x; d0[p][1] = b0a.y; d0[p][2] = b0a.z; d0[p][3] = b0a.w; d0[p][4] = b0b.x; d0[p][5] = b0b.y; d0[p][6] = b0b.z; d0[p][7] = b0b.w;
+            d1[p][0] = b1a.x; d1[p][1] = b1a.y; d1[p][2] = b1a.z; d1[p][3] = b1a.w; d1[p][4] = b1b.x; d1[p][5] = b1b.y; d1[p][6] = b1b.z; d1[p][7] = b1b.w;
+        }
+    };
+    constexpr bool HOIST = MT <= 2 && NP == 1;       // (the wide shapes hold too many accumulators for the early operands, and have the blocks to hide the latency)
+    const int NWr = (int)(blockDim.x >> 6);
+    constexpr bool HOIST2 = HOIST && MT == 1;        // groups of <= 16 streams: round 1's operands too (K = 1536: 24 chunks on 12 waves)
+    unsigned w0b[HOIST2 ? NP : 1][8], w1b[HOIST2 ? NP : 1][8];
+    if (HOIST && wave < nch) load_w(wave, w0, w1);
+    if constexpr (HOIST2) { if (wave + NWr < nch) load_w(wave + NWr, w0b, w1b); }
+    constexpr bool PFA = HOIST && NORM == 0;
+    constexpr bool PFA2 = PFA && HOIST2;
+    f32x4 apf[PFA ? MT : 1][4], apf2[PFA2 ? MT : 1][4];
+    if (PFA && wave < nch) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const f32x4* ap = reinterpret_cast<const f32x4*>(a.A + (size_t)min(m0 + m * 16 + li, a.M - 1) * a.lda + wave * 64 + lg * 16);
+            apf[m][0] = ap[0]; apf[m][1] = ap[1]; apf[m][2] = ap[2]; apf[m][3] = ap[3];
+        }
+    }
+    if (PFA2 && wave + NWr < nch) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const f32x4* ap = reinterpret_cast<const f32x4*>(a.A + (size_t)min(m0 + m * 16 + li, a.M - 1) * a.lda + (wave + NWr) * 64 + lg * 16);
+            apf2[m][0] = ap[0]; apf2[m][1] = ap[1]; apf2[m][2] = ap[2]; apf2[m][3] = ap[3];
+        }
+    }
+    int pos_pf = 0; float c_pf[NP], s_pf[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { c_pf[p] = 0.0f; s_pf[p] = 0.0f; }
+    if (EPI == EPI_ROPE && a.pos_dev && tid < 256) {
+        pos_pf = *a.pos_dev;                         // (every shape: two scalars per pair)
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            if ((n0[p] >> 6) < a.n_heads + a.n_kv) { const int i = (n0[p] & 63) + (tid & 15); c_pf[p] = a.cs[(size_t)pos_pf * 32 + i]; s_pf[p] = a.sn[(size_t)pos_pf * 32 + i]; }
+    }
     // NORM == 2 (single round: nch <= NW, MT <= 2): the wave that owns chunk c reads x[rows][chunk c] once, for the sum of squares AND as
     // its A operand.  The canonical chunk sum p = p + x_k * x_k (product rounded, then added, k ascending) is an MFMA chain with B = 1:
     // fma(x_k^2, 1, p) rounds x_k^2 + p once, exactly like the add.  No separate pass over the rows, no serial 64-long chains.
@@ -185,14 +232,14 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
         const int c = c0 + wave;
         f32x4 acc0[NP][MT], acc1[NP][MT];
         if (c < nch) {
-            unsigned w0[NP][8], w1[NP][8];
+            if (!HOIST || c0 > (HOIST2 ? NW : 0)) load_w(c, w0, w1);              // (HOIST: round 0's slab — HOIST2: round 1's too — was requested at the top of the kernel)
+            if constexpr (HOIST2) {
+                if (c0 == NW) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const uint4* b0p = reinterpret_cast<const uint4*>(a.Wd + (size_t)(n0[p] + li) * K + c * 64 + lg * 16);
-                const uint4* b1p = reinterpret_cast<const uint4*>(a.Wd + (size_t)(n1[p] + li) * K + c * 64 + lg * 16);
-                const uint4 b0a = b0p[0], b0b = b0p[1], b1a = b1p[0], b1b = b1p[1];
-                w0[p][0] = b0a.x; w0[p][1] = b0a.y; w0[p][2] = b0a.z; w0[p][3] = b0a.w; w0[p][4] = b0b.x; w0[p][5] = b0b.y; w0[p][6] = b0b.z; w0[p][7] = b0b.w;
-                w1[p][0] = b1a.x; w1[p][1] = b1a.y; w1[p][2] = b1a.z; w1[p][3] = b1a.w; w1[p][4] = b1b.x; w1[p][5] = b1b.y; w1[p][6] = b1b.z; w1[p][7] = b1b.w;
+                    for (int p = 0; p < NP; ++p)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { w0[p][e] = w0b[p][e]; w1[p][e] = w1b[p][e]; }
+                }
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -208,6 +255,10 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
                     const float mv = nm[m * 16 + li];
 #pragma unroll
                     for (int t = 0; t < 16; ++t) av[t >> 2][t & 3] = xr[4 * t] / mv * cz_bf16_to_f32(wr[4 * t]);
+                } else if (PFA && c0 == 0) {
+                    av[0] = apf[PFA ? m : 0][0]; av[1] = apf[PFA ? m : 0][1]; av[2] = apf[PFA ? m : 0][2]; av[3] = apf[PFA ? m : 0][3];
+                } else if (PFA2 && c0 == NW) {
+                    av[0] = apf2[PFA2 ? m : 0][0]; av[1] = apf2[PFA2 ? m : 0][1]; av[2] = apf2[PFA2 ? m : 0][2]; av[3] = apf2[PFA2 ? m : 0][3];
                 } else {
                     const f32x4* ap = reinterpret_cast<const f32x4*>(a.A + (size_t)arow * a.lda + c * 64 + lg * 16);
                     av[0] = ap[0]; av[1] = ap[1]; av[2] = ap[2]; av[3] = ap[3];
@@ -282,10 +333,10 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
             a.C[(size_t)row * a.ldc + kq_index(n0[p] + cc)] = cz_siluf(t0) * t1;      // silu(gate) * up  (llama.rs MLP)
         } else {
             cz_rope_desc d = a.descs[row];           // one row per stream
-            const int pos = a.pos_dev ? *a.pos_dev : d.pos0;
+            const int pos = a.pos_dev ? pos_pf : d.pos0;
             const int head = n0[p] >> 6, i = (n0[p] & 63) + cc;                       // rotation index i in [0, 32)
             if (head < a.n_heads + a.n_kv) {
-                const float c_ = a.cs[(size_t)pos * 32 + i], s_ = a.sn[(size_t)pos * 32 + i];
+                const float c_ = a.pos_dev ? c_pf[p] : a.cs[(size_t)pos * 32 + i], s_ = a.pos_dev ? s_pf[p] : a.sn[(size_t)pos * 32 + i];
                 const float aa = t0 * c_, bb = t1 * s_, c2 = t0 * s_, dd = t1 * c_;      // candle rope: products rounded separately
                 const float o1 = aa - bb, o2 = c2 + dd;
                 if (head < a.n_heads) {
@@ -487,6 +538,7 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : 4)) void dec_attn
     const int nch_max = (s_stride - 4) >> 6;
     float* qs = smem;                                   // [rep][64]
     float* S = qs + rep * 64;                           // [rep][s_stride]  e, then p
+    constexpr bool DEEP = DA_WAVES == 16 && DA_MAXC == 2 && rep == 1;   // small grids, one block per QUERY head: every load of a chunk in flight at once (see phase 1; rep > 1 would spill under the 128-register cap of 16 waves)
     constexpr bool LONG = DA_MAXC > 4;                   // (rounds of DA_WAVES chunk partials instead of all nch_max at once)
     constexpr int CS = DA_WAVES * DA_MAXC;               // chunks per block = stride of the chunk sums
     float* part = S + rep * s_stride;                   // [nch_max][rep][64]   chunk partials of P.V ([DA_WAVES][rep][64] per round when LONG)
@@ -510,8 +562,7 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : 4)) void dec_attn
                 // transposed cache: for every d the 64 lanes (keys) read 256 contiguous bytes.  Four real (not unrolled) rounds of 16 d keep
                 // the kernel under 128 VGPRs -> two blocks per CU: one block's softmax phase overlaps the other's loads, and the 384 blocks
                 // of a 128-stream step are resident at once instead of running in one and a half rounds
-#pragma unroll 1
-                for (int g = 0; g < 4; ++g) {
+                auto k_round = [&](const int g) {
                     float kreg[16];
                     if (sd.kt_stride) {
 #pragma unroll
@@ -532,6 +583,13 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : 4)) void dec_attn
                                 s[h] = cz_fma(qv[2], kv[2], s[h]); s[h] = cz_fma(qv[3], kv[3], s[h]);
                             }
                     }
+                                };
+                if (DEEP) {          // the 16-wave shape of small grids (e.g. ONE stream): a block is alone on its CU, four rounds = four dependent round trips;
+#pragma unroll                       // fully unrolled, the chunk's 64 loads are in flight at once
+                    for (int g = 0; g < 4; ++g) k_round(g);
+                } else {
+#pragma unroll 1
+                    for (int g = 0; g < 4; ++g) k_round(g);
                 }
 #pragma unroll
                 for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) { sc[i][h] = s[h] * 0.125f; lm[h] = sc[i][h] > lm[h] ? sc[i][h] : lm[h]; }
@@ -610,8 +668,7 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : 4)) void dec_attn
             // the 64-key slab of this lane's column in four real rounds of 16 keys (register budget, see phase 1).  Unconditional loads (row
             // index clamped) + select afterwards: a per-element "load or 0" on a runtime bound makes hipcc branch around every load and wait
             // for each one.  Keys past nk have p == 0 (exp(-inf)) and v == 0: fma(0, 0, acc) == acc, so the chain needs no guard.
-#pragma unroll 1
-            for (int g = 0; g < 4; ++g) {
+            auto v_round = [&](const int g) {
                 float vreg[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) { const int jx = g * 16 + j; const int jj = jx < jend ? jx : jend - 1; vreg[j] = __builtin_nontemporal_load(vp + (size_t)jj * sd.kv_stride); }
@@ -627,6 +684,13 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : 4)) void dec_attn
 #pragma unroll
                         for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) acc[h] = cz_fma(pv[h][u], vreg[4 * j4 + u], acc[h]);
                 }
+                        };
+            if (DEEP) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) v_round(g);
+            } else {
+#pragma unroll 1
+                for (int g = 0; g < 4; ++g) v_round(g);
             }
 #pragma unroll
             for (int h = 0; h < DA_MAXREP; ++h) if (h < rep) part[((LONG ? wave : c) * rep + h) * 64 + lane] = acc[h];

@@ -56,22 +56,17 @@ __device__ __forceinline__ int mid_xcd_remap(int bid, int nblocks) {    // block
 // EPI = 2 (TN = 1): the fused QKV projection with the head rows reordered by cz_launch_k2_pack(rot_heads = n_heads + n_kv): RoPE
 // (candle_nn::rotary_emb::rope, non-interleaved halves, products rounded separately) in the epilogue; q goes to C, k (rotated) and v
 // straight to the stream's KV cache at *pos_dev — what rope_kernel did in a launch of its own.
+// EPI = 3: C = relu(A.W^T)^2 (the RWKV7 channel-mix key projection, rwkv7.rs:426).
+// The tile (bm, bn) of one problem; the kernels below pick the tile.
 template <int TN, int EPI, int NW, bool PF>
-__global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : 1) void gemm_mid_kernel(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Wk,
-                                                           float* __restrict__ C, int ldc, const float* __restrict__ R, int ldr,
-                                                           int M, int N, int K, int nbx, int nblocks, int colmaj, mid_rope_args ra_) {
+__device__ __forceinline__ void gemm_mid_body(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Wk,
+                                              float* __restrict__ C, int ldc, const float* __restrict__ R, int ldr,
+                                              int M, int N, int K, const int bm, const int bn, const mid_rope_args& ra_) {
     static_assert(TN * 1024 <= 32 * MID_LDK, "a wave's partial tiles are parked in its own activation tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* As = smem + wave * (32 * MID_LDK);                            // wave-private activation tile [32][MID_LDK]; after the chain: this wave's partial tiles
     int* consumed = reinterpret_cast<int*>(smem + NW * (32 * MID_LDK));  // round up to which wave 0 has taken the partials over
-    // An XCD (blocks b, b + 8, ...: speed only) takes a contiguous range of tiles.  Row-major numbering gives it a few row tiles x ALL column
-    // tiles: its L2 fetches the whole weight panel and 1/8 of the activations; column-major (colmaj) a few column tiles x all row tiles: 1/8 of
-    // the weights, all the activations.  The launcher picks the order that fetches fewer bytes over the eight L2s (gate|up at 512 rows:
-    // 3.5 MB of weights x 8 against 1.2 MB of activations x 8).
-    const int sid = mid_xcd_remap(blockIdx.x, nblocks);
-    const int nby = nblocks / nbx;
-    const int bm = colmaj ? sid % nby : sid / nbx, bn = colmaj ? sid / nby : sid % nbx;
     const int lr = lane & 31, lh = lane >> 5;
     const int nk = K >> 6, rounds = (nk + NW - 1) / NW;
     const int srow = lane >> 3, sg = lane & 7;                           // staging: 8 rows x 8 k-groups per pass, 4 passes
@@ -244,10 +239,42 @@ __global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : 1) void gemm_mi
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float v = R ? tot[j][r] + rv[r] : tot[j][r];
+            float v = R ? tot[j][r] + rv[r] : tot[j][r];
+            if (EPI == 3) { const float z = tot[j][r] > 0.0f ? tot[j][r] : 0.0f; v = z * z; }
             if (row < M) C[(size_t)row * ldc + col] = v;
         }
     }
+}
+
+template <int TN, int EPI, int NW, bool PF>
+__global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : 1) void gemm_mid_kernel(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Wk,
+                                                           float* __restrict__ C, int ldc, const float* __restrict__ R, int ldr,
+                                                           int M, int N, int K, int nbx, int nblocks, int colmaj, mid_rope_args ra_) {
+    // An XCD (blocks b, b + 8, ...: speed only) takes a contiguous range of tiles.  Row-major numbering gives it a few row tiles x ALL column
+    // tiles: its L2 fetches the whole weight panel and 1/8 of the activations; column-major (colmaj) a few column tiles x all row tiles: 1/8 of
+    // the weights, all the activations.  The launcher picks the order that fetches fewer bytes over the eight L2s (gate|up at 512 rows:
+    // 3.5 MB of weights x 8 against 1.2 MB of activations x 8).
+    const int sid = mid_xcd_remap(blockIdx.x, nblocks);
+    const int nby = nblocks / nbx;
+    const int bm = colmaj ? sid % nby : sid / nbx, bn = colmaj ? sid / nby : sid % nbx;
+    gemm_mid_body<TN, EPI, NW, PF>(A, lda, Wk, C, ldc, R, ldr, M, N, K, bm, bn, ra_);
+}
+
+// Several independent plain GEMMs that share M in ONE launch (the RWKV7 time-mix: seven projections of differently mixed inputs, then four
+// LoRA up-projections): tile t of the launch belongs to the problem z with tile0[z] <= t < tile0[z + 1]; column-major inside a problem (a
+// few hundred rows against 768-wide weight panels: the weights are the larger operand).
+#define MID_GROUP_MAX 8
+struct mid_prob { const float* A; const uint16_t* Wk; float* C; int lda, ldc, N, K; };
+struct mid_group { mid_prob p[MID_GROUP_MAX]; int tile0[MID_GROUP_MAX + 1]; int n; };
+template <int NW, bool PF>
+__global__ __launch_bounds__(NW * 64, 1) void gemm_mid_group_kernel(mid_group g, int M, int nblocks) {
+    const int sid = mid_xcd_remap(blockIdx.x, nblocks);
+    int z = 0;
+#pragma unroll
+    for (int q = 1; q < MID_GROUP_MAX; ++q) if (q < g.n && sid >= g.tile0[q]) z = q;
+    const mid_prob pr = g.p[z];
+    const int local = sid - g.tile0[z], nby = (M + 31) / 32;
+    gemm_mid_body<1, 0, NW, PF>(pr.A, pr.lda, pr.Wk, pr.C, pr.ldc, nullptr, 0, M, pr.N, pr.K, local % nby, local / nby, mid_rope_args{});
 }
 
 int g_mid_colmaj = -1;        // tuning knob (cz_debug_set "mid_colmaj"): -1 = by operand sizes, 0 = row-major tile order, 1 = column-major
@@ -280,6 +307,9 @@ hipError_t cz_gemm_mid_prepare() {
     hipError_t e = mid_prepare_epi<1, 0>();
     if (e == hipSuccess) e = mid_prepare_epi<2, 1>();
     if (e == hipSuccess) e = mid_prepare_epi<1, 2>();
+    if (e == hipSuccess) e = mid_prepare_epi<1, 3>();
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_mid_group_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)((size_t)(4 * 32 * MID_LDK + 4) * sizeof(float)));
     return e;
 }
 // K groups per block.  Measured on 512-row groups (profiles/r02_microbench/call24_*): four groups with operand prefetch beat a wave per
@@ -315,4 +345,30 @@ hipError_t cz_launch_gemm_mid_qkv(hipStream_t st, const float* A, int lda, const
     if (K % 64 != 0 || !descs || !cs || !sn) return hipErrorInvalidValue;
     mid_rope_args ra{descs, cs, sn, pos_dev, kv_off, n_heads, n_kv};
     return launch_mid<1, 2>(st, A, lda, Wk, Q, ldq, nullptr, 0, M, (n_heads + 2 * n_kv) * 64, K, ra);
+}
+
+// C[M][N] = relu(A . W^T)^2
+hipError_t cz_launch_gemm_mid_relusq(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* C, int ldc, int M, int N, int K) {
+    if (M <= 0) return hipSuccess;
+    if (K % 64 != 0 || N % 32 != 0) return hipErrorInvalidValue;
+    return launch_mid<1, 3>(st, A, lda, Wk, C, ldc, nullptr, 0, M, N, K);
+}
+// nprob plain GEMMs C_i[M][N_i] = A_i . W_i^T sharing M, one launch (four K groups per block)
+hipError_t cz_launch_gemm_mid_group(hipStream_t st, int nprob, const float* const* A, const int* lda, const uint16_t* const* Wk, float* const* C, const int* ldc,
+                                    const int* N, const int* K, int M) {
+    if (M <= 0 || nprob <= 0) return hipSuccess;
+    if (nprob > MID_GROUP_MAX) return hipErrorInvalidValue;
+    mid_group g{};
+    const int nby = (M + 31) / 32;
+    int tiles = 0;
+    for (int i = 0; i < nprob; ++i) {
+        if (N[i] % 32 || K[i] % 64) return hipErrorInvalidValue;
+        g.p[i] = mid_prob{A[i], Wk[i], C[i], lda[i], ldc[i], N[i], K[i]};
+        g.tile0[i] = tiles; tiles += nby * (N[i] / 32);
+    }
+    for (int i = nprob; i <= MID_GROUP_MAX; ++i) g.tile0[i] = tiles;
+    g.n = nprob;
+    const size_t smem = (size_t)(4 * 32 * MID_LDK + 4) * sizeof(float);
+    hipLaunchKernelGGL((gemm_mid_group_kernel<4, true>), dim3(tiles), dim3(4 * 64), smem, st, g, M, tiles);
+    return hipGetLastError();
 }

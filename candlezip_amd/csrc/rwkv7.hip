@@ -36,6 +36,8 @@ struct RwLayer {
     uint16_t *r, *k, *v, *o, *w1, *w2, *a1, *a2, *v1, *v2, *g1, *g2, *fk, *fv;
     // the same matrices in natural k order, [pad64(N)][pad64(K)] zero-padded: operands of the tiled big-M GEMM (sequence-parallel encode)
     uint16_t *r_n, *k_n, *v_n, *o_n, *w1_n, *w2_n, *a1_n, *a2_n, *v1_n, *v2_n, *g1_n, *g2_n, *fk_n, *fv_n;
+    // ... and packed for the K-group GEMM of wide decode groups (kernels_gemm_mid.hip, "k2" order), same padded shapes
+    uint16_t *r_2, *k_2, *v_2, *o_2, *w1_2, *w2_2, *a1_2, *a2_2, *v1_2, *v2_2, *g1_2, *g2_2, *fk_2, *fv_2;
     // vectors (bf16)
     uint16_t *pre_w, *pre_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b, *gn_w, *gn_b, *x_r, *x_w, *x_k, *x_v, *x_a, *x_g, *w0, *a0, *v0, *k_k, *k_a,
         *r_k, *fx_k;
@@ -160,6 +162,17 @@ __global__ __launch_bounds__(64) void rw_state_kernel(const float* __restrict__ 
                                                       const unsigned char* __restrict__ mask, int B, int out_kq) {
     __shared__ float kk[64], av[64], kv[64], wv[64], rv[64], vv[64], yv[64];
     const int b = blockIdx.x, h = blockIdx.y, i = threadIdx.x, c = h * 64 + i;
+    // the 16 KB state tile is requested FIRST: its round trip then overlaps the prologue below (the per-token terms, two 64-long chains and
+    // two barriers: ~2 us that used to precede it)
+    // state tile of a head in HBM: element (i, j) at ((j >> 2) * 64 + i) * 4 + (j & 3) — lane i's sixteen 16-B pieces of ITS row sit 1 KB apart,
+    // so load / store j4 moves one contiguous KB per wave (row-major rows of 256 B would be 64 lanes in 64 different rows: ~17x slower, guide)
+    float* Srow = S + ((size_t)b * gridDim.y + h) * 4096 + (size_t)i * 4;
+    float srow[64];
+#pragma unroll
+    for (int j4 = 0; j4 < 16; ++j4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(Srow + 256 * j4);
+        srow[4 * j4] = t4.x; srow[4 * j4 + 1] = t4.y; srow[4 * j4 + 2] = t4.z; srow[4 * j4 + 3] = t4.w;
+    }
     const float* p = P + (size_t)b * ldp;
     const float* l2 = L2 + (size_t)b * 4 * C;
     const float r = p[c], kraw = p[C + c];
@@ -190,15 +203,8 @@ __global__ __launch_bounds__(64) void rw_state_kernel(const float* __restrict__ 
     __syncthreads();
     kk[i] = kkn; av[i] = a; kv[i] = k; wv[i] = w; rv[i] = r; vv[i] = v;
     __syncthreads();
-    // state tile of a head in HBM: element (i, j) at ((j >> 2) * 64 + i) * 4 + (j & 3) — lane i's sixteen 16-B pieces of ITS row sit 1 KB apart,
-    // so load / store j4 moves one contiguous KB per wave (row-major rows of 256 B would be 64 lanes in 64 different rows: ~17x slower, guide)
-    float* Srow = S + ((size_t)b * gridDim.y + h) * 4096 + (size_t)i * 4;
-    float srow[64];
-#pragma unroll
-    for (int j4 = 0; j4 < 16; ++j4) {
-        const float4 t4 = *reinterpret_cast<const float4*>(Srow + 256 * j4);
-        srow[4 * j4] = t4.x; srow[4 * j4 + 1] = t4.y; srow[4 * j4 + 2] = t4.z; srow[4 * j4 + 3] = t4.w;
-    }
+    float al = 0.0f;                                                                          // the bonus term's r . (k r_k) does not depend on the state: here, under the state load
+    for (int j = 0; j < 64; ++j) { const float q = rv[j] * kv[j] * cz_bf16_to_f32(L.r_k[h * 64 + j]); al = al + q; }
     float t = 0.0f;
 #pragma unroll
     for (int j = 0; j < 64; ++j) t = cz_fma(srow[j], kk[j], t);                           // (S @ kk)[i]
@@ -223,9 +229,8 @@ __global__ __launch_bounds__(64) void rw_state_kernel(const float* __restrict__ 
     __syncthreads();
     yv[i] = cen * cen;
     __syncthreads();
-    float s2 = 0.0f, al = 0.0f;
+    float s2 = 0.0f;
     for (int j = 0; j < 64; ++j) s2 = s2 + yv[j];
-    for (int j = 0; j < 64; ++j) { const float q = rv[j] * kv[j] * cz_bf16_to_f32(L.r_k[h * 64 + j]); al = al + q; }
     const float den = sqrtf(s2 * 0.015625f + (float)64e-5);
     const float gn = cen / den * cz_bf16_to_f32(L.gn_w[c]) + cz_bf16_to_f32(L.gn_b[c]);
     const float ad = al * v;
@@ -334,7 +339,7 @@ cz_status cz_rwkv7_build(cz_session* s, const cz_model_desc* desc) {
         cz_set_error("tensor %s not found in the safetensors files", name.c_str());
         return CZ_ERR_IO;
     };
-    auto mat = [&](const std::string& name, uint16_t** out, uint16_t** out_nat, int N, int K, float stdv) -> cz_status {
+    auto mat = [&](const std::string& name, uint16_t** out, uint16_t** out_nat, uint16_t** out_k2, int N, int K, float stdv) -> cz_status {
         const int Kp = pad64(K), Np = pad64(N);
         CZCHK(rw_alloc(m, (void**)out, (size_t)N * Kp * 2));
         CZCHK(rw_alloc(m, (void**)out_nat, (size_t)Np * Kp * 2));
@@ -343,6 +348,10 @@ cz_status cz_rwkv7_build(cz_session* s, const cz_model_desc* desc) {
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(rw_pad_kernel, dim3(1024), dim3(256), 0, s->stream, tmp, *out_nat, (size_t)N, K, (size_t)Np, Kp);
         HIPCHK(hipGetLastError());
+        if (out_k2) {
+            CZCHK(rw_alloc(m, (void**)out_k2, (size_t)Np * Kp * 2));
+            HIPCHK(cz_launch_k2_pack(s->stream, *out_nat, *out_k2, (size_t)Np, Kp, 0));
+        }
         // `tmp` is reused by the next matrix.  Synthetic tensors are generated on s->stream (ordered behind this kernel), but a checkpoint
         // tensor arrives by a blocking hipMemcpy on the null stream, which a non-blocking stream does not wait for: drain the pack first
         if (!synthetic) HIPCHK(hipStreamSynchronize(s->stream));
@@ -362,27 +371,27 @@ cz_status cz_rwkv7_build(cz_session* s, const cz_model_desc* desc) {
         if (i == 0) { CZCHK(vec(p + "pre_norm.weight", &l.pre_w, C, 0.1f, 1.0f)); CZCHK(vec(p + "pre_norm.bias", &l.pre_b, C, 0.02f, 0.0f)); }
         CZCHK(vec(p + "attn_norm.weight", &l.ln1_w, C, 0.1f, 1.0f)); CZCHK(vec(p + "attn_norm.bias", &l.ln1_b, C, 0.02f, 0.0f));
         CZCHK(vec(p + "ffn_norm.weight", &l.ln2_w, C, 0.1f, 1.0f));  CZCHK(vec(p + "ffn_norm.bias", &l.ln2_b, C, 0.02f, 0.0f));
-        CZCHK(mat(p + "attn.r_proj.weight", &l.r, &l.r_n, C, C, 0.03f)); CZCHK(mat(p + "attn.k_proj.weight", &l.k, &l.k_n, C, C, 0.03f));
-        CZCHK(mat(p + "attn.v_proj.weight", &l.v, &l.v_n, C, C, 0.03f)); CZCHK(mat(p + "attn.o_proj.weight", &l.o, &l.o_n, C, C, 0.03f));
+        CZCHK(mat(p + "attn.r_proj.weight", &l.r, &l.r_n, &l.r_2, C, C, 0.03f)); CZCHK(mat(p + "attn.k_proj.weight", &l.k, &l.k_n, &l.k_2, C, C, 0.03f));
+        CZCHK(mat(p + "attn.v_proj.weight", &l.v, &l.v_n, &l.v_2, C, C, 0.03f)); CZCHK(mat(p + "attn.o_proj.weight", &l.o, &l.o_n, &l.o_2, C, C, 0.03f));
         CZCHK(vec(p + "attn.g_norm.weight", &l.gn_w, C, 0.1f, 1.0f)); CZCHK(vec(p + "attn.g_norm.bias", &l.gn_b, C, 0.02f, 0.0f));
         CZCHK(vec(p + "attn.x_r", &l.x_r, C, 0.15f, 0.5f)); CZCHK(vec(p + "attn.x_w", &l.x_w, C, 0.15f, 0.5f)); CZCHK(vec(p + "attn.x_k", &l.x_k, C, 0.15f, 0.5f));
         CZCHK(vec(p + "attn.x_v", &l.x_v, C, 0.15f, 0.5f)); CZCHK(vec(p + "attn.x_a", &l.x_a, C, 0.15f, 0.5f)); CZCHK(vec(p + "attn.x_g", &l.x_g, C, 0.15f, 0.5f));
-        CZCHK(mat(p + "attn.w_lora.lora.0.weight", &l.w1, &l.w1_n, c.decay_rank, C, 0.05f)); CZCHK(mat(p + "attn.w_lora.lora.2.weight", &l.w2, &l.w2_n, C, c.decay_rank, 0.05f));
+        CZCHK(mat(p + "attn.w_lora.lora.0.weight", &l.w1, &l.w1_n, &l.w1_2, c.decay_rank, C, 0.05f)); CZCHK(mat(p + "attn.w_lora.lora.2.weight", &l.w2, &l.w2_n, &l.w2_2, C, c.decay_rank, 0.05f));
         CZCHK(vec(p + "attn.w_lora.lora.2.bias", &l.w0, C, 1.0f, 0.0f));
-        CZCHK(mat(p + "attn.a_lora.lora.0.weight", &l.a1, &l.a1_n, c.a_rank, C, 0.05f)); CZCHK(mat(p + "attn.a_lora.lora.2.weight", &l.a2, &l.a2_n, C, c.a_rank, 0.05f));
+        CZCHK(mat(p + "attn.a_lora.lora.0.weight", &l.a1, &l.a1_n, &l.a1_2, c.a_rank, C, 0.05f)); CZCHK(mat(p + "attn.a_lora.lora.2.weight", &l.a2, &l.a2_n, &l.a2_2, C, c.a_rank, 0.05f));
         CZCHK(vec(p + "attn.a_lora.lora.2.bias", &l.a0, C, 0.5f, 0.0f));
         if (i > 0) {                                                    // rwkv7.rs:146-152 (`contains_tensor`): the synthetic model mirrors the oracle
             l.has_v = 1;
-            CZCHK(mat(p + "attn.v_lora.lora.0.weight", &l.v1, &l.v1_n, c.v_rank, C, 0.05f)); CZCHK(mat(p + "attn.v_lora.lora.2.weight", &l.v2, &l.v2_n, C, c.v_rank, 0.05f));
+            CZCHK(mat(p + "attn.v_lora.lora.0.weight", &l.v1, &l.v1_n, &l.v1_2, c.v_rank, C, 0.05f)); CZCHK(mat(p + "attn.v_lora.lora.2.weight", &l.v2, &l.v2_n, &l.v2_2, C, c.v_rank, 0.05f));
             CZCHK(vec(p + "attn.v_lora.lora.2.bias", &l.v0, C, 0.5f, 1.0f));
         }
-        CZCHK(mat(p + "attn.g_lora.lora.0.weight", &l.g1, &l.g1_n, c.gate_rank, C, 0.05f)); CZCHK(mat(p + "attn.g_lora.lora.2.weight", &l.g2, &l.g2_n, C, c.gate_rank, 0.05f));
+        CZCHK(mat(p + "attn.g_lora.lora.0.weight", &l.g1, &l.g1_n, &l.g1_2, c.gate_rank, C, 0.05f)); CZCHK(mat(p + "attn.g_lora.lora.2.weight", &l.g2, &l.g2_n, &l.g2_2, C, c.gate_rank, 0.05f));
         CZCHK(vec(p + "attn.k_k", &l.k_k, C, 0.1f, 0.85f)); CZCHK(vec(p + "attn.k_a", &l.k_a, C, 0.1f, 1.0f)); CZCHK(vec(p + "attn.r_k", &l.r_k, C, 0.05f, 0.0f));
         CZCHK(vec(p + "ffn.x_k", &l.fx_k, C, 0.15f, 0.5f));
-        CZCHK(mat(p + "ffn.key.weight", &l.fk, &l.fk_n, F, C, 0.03f)); CZCHK(mat(p + "ffn.value.weight", &l.fv, &l.fv_n, C, F, 0.03f));
+        CZCHK(mat(p + "ffn.key.weight", &l.fk, &l.fk_n, &l.fk_2, F, C, 0.03f)); CZCHK(mat(p + "ffn.value.weight", &l.fv, &l.fv_n, &l.fv_2, C, F, 0.03f));
     }
     CZCHK(vec("model.norm.weight", &m->lno_w, C, 0.1f, 1.0f)); CZCHK(vec("model.norm.bias", &m->lno_b, C, 0.02f, 0.0f));
-    CZCHK(mat("lm_head.weight", &m->head, &m->head_n, V, C, desc->synthetic_embed_std));
+    CZCHK(mat("lm_head.weight", &m->head, &m->head_n, nullptr, V, C, desc->synthetic_embed_std));
     HIPCHK(hipStreamSynchronize(s->stream));
     return CZ_OK;
 }
@@ -514,6 +523,7 @@ static cz_status rw_step_wide(cz_session* s, int B) {
     const int C = c.hidden, F = c.d_ffn, H = C / 64, Bc = m->B;
     const int pw = pad64(c.decay_rank), pa = pad64(c.a_rank), pg = 128, pv = pad64(c.v_rank);
     const int ow = 3 * C, oa = ow + pw, og = oa + pa, ov = og + pg, ldp = ov + pv;
+    const int ng = pad64(c.gate_rank);                 // rows of g1 / columns of g2 that exist in the padded weight copies (the activation slot is 128 wide)
     hipStream_t st = s->stream;
     const size_t shm = (size_t)(C + 64) * sizeof(float);
     float *TW = m->lora1a, *TA = TW + (size_t)Bc * 64, *TG = TA + (size_t)Bc * 64, *TV = TG + (size_t)Bc * 128;
@@ -524,6 +534,7 @@ static cz_status rw_step_wide(cz_session* s, int B) {
         return e;
     };
     const double st_bytes = (double)B * H * 2.0 * 64 * 64 * 4;
+    const bool mid = s->rwkv_wide_mode == 1;          // 1: the K-group GEMM (32 x 32 tiles, grouped launches); 0: the tiled big-M kernel, one launch per projection
     s->prof_begin(PK_RW_PREP);
     HIPCHK(cz_launch_embed(st, m->tok, m->emb, m->x, B, C));
     for (int l = 0; l < c.n_layers; ++l) {
@@ -535,36 +546,71 @@ static cz_status rw_step_wide(cz_session* s, int B) {
         HIPCHK(hipGetLastError());
         s->prof_end(0, (double)B * C * 4 * 9);
         auto mixp = [&](int j) { return m->mix + (size_t)j * Bc * C; };                     // [6][Bc][C]: r w k v a g
+        if (mid) {   // seven projections of the six mixed inputs in ONE launch of 32 x 32 tiles (r, k, v and the LoRA down-projections w1, a1, g1 (, v1))
+            const float* A[7] = {mixp(0), mixp(2), mixp(3), mixp(1), mixp(4), mixp(5), mixp(3)};
+            const int lda[7] = {C, C, C, C, C, C, C};
+            const uint16_t* W[7] = {y.r_2, y.k_2, y.v_2, y.w1_2, y.a1_2, y.g1_2, y.v1_2};
+            float* Cc[7] = {m->proj + 0, m->proj + C, m->proj + 2 * C, m->proj + ow, m->proj + oa, m->proj + og, m->proj + ov};
+            const int ldc[7] = {ldp, ldp, ldp, ldp, ldp, ldp, ldp};
+            const int N[7] = {C, C, C, pw, pa, ng, pv};
+            const int K[7] = {C, C, C, C, C, C, C};
+            s->prof_begin(PK_RW_GEMM);
+            HIPCHK(cz_launch_gemm_mid_group(st, y.has_v ? 7 : 6, A, lda, W, Cc, ldc, N, K, B));
+            s->prof_end(2.0 * B * (double)C * (3 * C + pw + pa + pg + (y.has_v ? pv : 0)), 2.0 * C * (3 * C + pw + pa + pg + pv) + (double)B * C * 4 * 10);
+        } else {
         HIPCHK(gemm(mixp(0), C, y.r_n, m->proj + 0, ldp, nullptr, C, C));
         HIPCHK(gemm(mixp(2), C, y.k_n, m->proj + C, ldp, nullptr, C, C));
         HIPCHK(gemm(mixp(3), C, y.v_n, m->proj + 2 * C, ldp, nullptr, C, C));
         HIPCHK(gemm(mixp(1), C, y.w1_n, m->proj + ow, ldp, nullptr, pw, C));
         HIPCHK(gemm(mixp(4), C, y.a1_n, m->proj + oa, ldp, nullptr, pa, C));
-        HIPCHK(gemm(mixp(5), C, y.g1_n, m->proj + og, ldp, nullptr, pg, C));
+        HIPCHK(gemm(mixp(5), C, y.g1_n, m->proj + og, ldp, nullptr, ng, C));
         if (y.has_v) HIPCHK(gemm(mixp(3), C, y.v1_n, m->proj + ov, ldp, nullptr, pv, C));
+        }
         s->prof_begin(PK_RW_PREP);
         hipLaunchKernelGGL(rw_lora_act_kernel, dim3(B), dim3(128), 0, st, m->proj, ldp, ow, oa, og, ov, c.decay_rank, c.a_rank, c.gate_rank, y.has_v ? c.v_rank : 0,
                            TW, TA, TG, TV, pw, pa, pg, pv, 0);
         HIPCHK(hipGetLastError());
         s->prof_end(0, (double)B * (pw + pa + pg + pv) * 8);
         float* L2 = m->lora2;                                                              // [Bc][4][C]: w_lora, a_lin, g, nu_lin
+        if (mid) {   // the four LoRA up-projections in one launch
+            const float* A[4] = {TW, TA, TG, TV};
+            const int lda[4] = {pw, pa, pg, pv};
+            const uint16_t* W[4] = {y.w2_2, y.a2_2, y.g2_2, y.v2_2};
+            float* Cc[4] = {L2 + 0, L2 + C, L2 + 2 * C, L2 + 3 * C};
+            const int ldc[4] = {4 * C, 4 * C, 4 * C, 4 * C};
+            const int N[4] = {C, C, C, C};
+            const int K[4] = {pw, pa, ng, pv};
+            s->prof_begin(PK_RW_GEMM);
+            HIPCHK(cz_launch_gemm_mid_group(st, y.has_v ? 4 : 3, A, lda, W, Cc, ldc, N, K, B));
+            s->prof_end(2.0 * B * (double)C * (pw + pa + pg + (y.has_v ? pv : 0)), 2.0 * C * (pw + pa + pg + pv) + (double)B * C * 4 * 5);
+        } else {
         HIPCHK(gemm(TW, pw, y.w2_n, L2 + 0, 4 * C, nullptr, C, pw));
         HIPCHK(gemm(TA, pa, y.a2_n, L2 + C, 4 * C, nullptr, C, pa));
-        HIPCHK(gemm(TG, pg, y.g2_n, L2 + 2 * C, 4 * C, nullptr, C, pg));
+        HIPCHK(gemm(TG, pg, y.g2_n, L2 + 2 * C, 4 * C, nullptr, C, ng));
         if (y.has_v) HIPCHK(gemm(TV, pv, y.v2_n, L2 + 3 * C, 4 * C, nullptr, C, pv));
+        }
         s->prof_begin(PK_RW_STATE);
         hipLaunchKernelGGL(rw_state_kernel, dim3(B, H), dim3(64), 0, st, m->proj, ldp, L2, y, l, C, S, m->v_first, m->att, m->mask, Bc, 0);
         HIPCHK(hipGetLastError());
         s->prof_end(0, st_bytes);
-        HIPCHK(gemm(m->att, C, y.o_n, m->x, C, m->x, C, C));                               // x = x + att
+        if (mid) {
+            s->prof_begin(PK_RW_GEMM);
+            HIPCHK(cz_launch_gemm_mid(st, m->att, C, y.o_2, m->x, C, m->x, C, B, C, C));
+            s->prof_end(2.0 * B * (double)C * C, 2.0 * C * C + (double)B * C * 12);
+        } else HIPCHK(gemm(m->att, C, y.o_n, m->x, C, m->x, C, C));                        // x = x + att
         s->prof_begin(PK_RW_PREP);
         hipLaunchKernelGGL(rw_prep_ffn_kernel, dim3(B), dim3(C), shm, st, m->x, y, c.norm_eps, fxp, m->xn, m->mask, 0);
         HIPCHK(hipGetLastError());
         s->prof_end(0, (double)B * C * 4 * 4);
         s->prof_begin(PK_RW_GEMM);
-        HIPCHK(cz_launch_gemm_relusq(st, m->xn, C, y.fk_n, m->ffk, F, B, F, C));
+        if (mid) HIPCHK(cz_launch_gemm_mid_relusq(st, m->xn, C, y.fk_2, m->ffk, F, B, F, C));
+        else HIPCHK(cz_launch_gemm_relusq(st, m->xn, C, y.fk_n, m->ffk, F, B, F, C));
         s->prof_end(2.0 * B * (double)C * F, 2.0 * C * F + (double)B * (C + F) * 4);
-        HIPCHK(gemm(m->ffk, F, y.fv_n, m->x, C, m->x, C, F));                              // x = x + ffn
+        if (mid) {
+            s->prof_begin(PK_RW_GEMM);
+            HIPCHK(cz_launch_gemm_mid(st, m->ffk, F, y.fv_2, m->x, C, m->x, C, B, C, F));
+            s->prof_end(2.0 * B * (double)C * F, 2.0 * C * F + (double)B * (C + F) * 4);
+        } else HIPCHK(gemm(m->ffk, F, y.fv_n, m->x, C, m->x, C, F));                       // x = x + ffn
     }
     s->prof_begin(PK_RW_PREP);
     hipLaunchKernelGGL(rw_ln_out_kernel, dim3(B), dim3(C), shm, st, m->x, m->lno_w, m->lno_b, c.norm_eps, m->xn, 0);

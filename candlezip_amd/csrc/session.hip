@@ -1169,7 +1169,7 @@ static cz_status make_lane(cz_session* p, cz_session** out) {
 }
 static void lane_inherit(const cz_session* s, cz_session* ls) {   // a lane runs with its parent's knobs
     ls->kv_ctx_cap = s->kv_ctx_cap; ls->serial_cdf = s->serial_cdf; ls->decode_v1 = s->decode_v1; ls->no_graph = s->no_graph; ls->force_big_gemm = s->force_big_gemm;
-    ls->max_batch_rows = s->max_batch_rows; ls->logit_batch_rows = s->logit_batch_rows; ls->step_sync = s->step_sync; ls->fuse_norm = s->fuse_norm; ls->wide_min_streams = s->wide_min_streams; ls->wide_mode = s->wide_mode; ls->dbg_skip = s->dbg_skip; ls->no_last_prune = s->no_last_prune; ls->rwkv_seq = s->rwkv_seq; ls->rwkv_wide_min = s->rwkv_wide_min;
+    ls->max_batch_rows = s->max_batch_rows; ls->logit_batch_rows = s->logit_batch_rows; ls->step_sync = s->step_sync; ls->fuse_norm = s->fuse_norm; ls->wide_min_streams = s->wide_min_streams; ls->wide_mode = s->wide_mode; ls->dbg_skip = s->dbg_skip; ls->no_last_prune = s->no_last_prune; ls->rwkv_seq = s->rwkv_seq; ls->rwkv_wide_min = s->rwkv_wide_min; ls->rwkv_wide_mode = s->rwkv_wide_mode;
 }
 // run `n_streams` streams as groups of <= max_streams on up to max_lanes lanes; group(ls, off, count) processes streams [off, off + count)
 template <class GroupFn>
@@ -1502,6 +1502,7 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "no_last_prune")) s->no_last_prune = (int)value;
     else if (!strcmp(key, "rwkv_seq")) s->rwkv_seq = (int)value;
     else if (!strcmp(key, "rwkv_wide_min")) s->rwkv_wide_min = (int)value;
+    else if (!strcmp(key, "rwkv_wide_mode")) s->rwkv_wide_mode = (int)value;
     else if (!strcmp(key, "rwkv_seq_rows")) g_rw_seq_rows = (int)value < 1 ? 1 : (int)value;
     else if (!strcmp(key, "mid_nw")) g_mid_nw = (int)value;
     else if (!strcmp(key, "mid_colmaj")) g_mid_colmaj = (int)value;
