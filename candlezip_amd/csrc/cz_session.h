@@ -6,7 +6,7 @@
 #include "../../include/candlezip.h"
 #include "cz_kernels.h"
 
-#define CZ_SYNC_EVERY 64     // decode loops wait for the device every this many tokens (bounds the packets queued behind the host; session.hip)
+#define CZ_SYNC_EVERY 8      // decode loops wait for the device every this many tokens (bounds the packets queued behind the host; session.hip)
 #define CZ_DEF_CTX 2048      // positions per stream the KV cache starts with (the reference's default sawtooth peaks at 1023, config 5's at 1535);
                              // a run that needs more (a re-prime interval > 1536) gets a cache sized for it, up to cz_ctx_limit()
 

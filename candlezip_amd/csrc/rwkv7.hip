@@ -29,6 +29,7 @@
     } while (0)
 #define CZCHK(expr) do { cz_status _s = (expr); if (_s != CZ_OK) return _s; } while (0)
 
+int g_rw_state_pad = 0;        // tuning knob (cz_debug_set "rw_state_pad"): extra dynamic LDS bytes per rw_state_kernel block (fewer waves per CU -> several generations of waves, whose load / compute / store phases then overlap)
 __host__ __device__ __forceinline__ int kq_idx(int k) { return (k & ~63) | ((k & 3) << 4) | ((k & 63) >> 2); }
 
 struct RwLayer {
@@ -156,16 +157,24 @@ __global__ void rw_lora_act_kernel(const float* __restrict__ P /*[B][ldp]*/, int
 }
 
 // state kernel: block = (stream, head), 64 lanes = state rows (rwkv7.rs:213-222, 231, 239-266, 289-323, 529-542)
-__global__ __launch_bounds__(64) void rw_state_kernel(const float* __restrict__ P /*[B][ldp]: r | k | v*/, int ldp, const float* __restrict__ L2 /*[B][4][C]: w a g nu*/,
-                                                      const RwLayer L, int layer, int C, float* __restrict__ S /*[B][H][64][64]*/,
+// Register discipline: the 64-float state row is the only large live set.  Everything a lane needs of the OTHER lanes goes through LDS as
+// a value each lane computed from its own element (kk^2, kk*a, r*k*r_k ...: the same products, rounded the same way, as when every lane
+// recomputed all 64 of them), the 64-long canonical sums then read one LDS array each, and barriers separate the stages — so that the
+// scheduler cannot hoist hundreds of LDS / global loads above the chains (it did: 256 VGPRs + scratch, one wave per SIMD, 3 TB/s).
+__global__ __launch_bounds__(64, 4) void rw_state_kernel(const float* __restrict__ P /*[B][ldp]: r | k | v*/, int ldp, const float* __restrict__ L2 /*[B][4][C]: w a g nu*/,
+                                                      const RwLayer L, int layer, int C, float* __restrict__ S /*[B][H] tiles*/,
                                                       float* __restrict__ v_first /*[B][C]*/, float* __restrict__ OUT /*[B][C] kq*/,
                                                       const unsigned char* __restrict__ mask, int B, int out_kq) {
-    __shared__ float kk[64], av[64], kv[64], wv[64], rv[64], vv[64], yv[64];
+    __shared__ __attribute__((aligned(16))) float bc[5][64];     // kk | kk*a | w | k | r   (as rw_seq_scan_kernel)
+    __shared__ __attribute__((aligned(16))) float tmp[64];
     const int b = blockIdx.x, h = blockIdx.y, i = threadIdx.x, c = h * 64 + i;
-    // the 16 KB state tile is requested FIRST: its round trip then overlaps the prologue below (the per-token terms, two 64-long chains and
-    // two barriers: ~2 us that used to precede it)
+    // A stream whose symbol was a literal does not step the model (src/main.rs:2347, :2832): nothing of its step is kept — state, token shift,
+    // v_first and logits are all masked — so its block leaves at once (block-uniform).  The stores below are therefore unconditional: with them
+    // inside a `mask` branch the compiler kept the old AND the new row alive (476 B of scratch per lane at 128 VGPRs).
+    if (mask && !mask[b]) return;
     // state tile of a head in HBM: element (i, j) at ((j >> 2) * 64 + i) * 4 + (j & 3) — lane i's sixteen 16-B pieces of ITS row sit 1 KB apart,
-    // so load / store j4 moves one contiguous KB per wave (row-major rows of 256 B would be 64 lanes in 64 different rows: ~17x slower, guide)
+    // so load / store j4 moves one contiguous KB per wave (row-major rows of 256 B would be 64 lanes in 64 different rows: ~17x slower, guide).
+    // Requested first: the round trip overlaps the per-token terms below.
     float* Srow = S + ((size_t)b * gridDim.y + h) * 4096 + (size_t)i * 4;
     float srow[64];
 #pragma unroll
@@ -184,53 +193,56 @@ __global__ __launch_bounds__(64) void rw_state_kernel(const float* __restrict__ 
     const float w = cz_expf(-cz_expf(wt));
     const float a = cz_sigmoidf(l2[C + c] + cz_bf16_to_f32(L.a0[c]));
     const float g = l2[2 * C + c];
-    if (layer == 0) { if (!mask || mask[b]) v_first[(size_t)b * C + c] = v; }
+    if (layer == 0) v_first[(size_t)b * C + c] = v;
     else if (L.has_v) {
         const float nu = cz_sigmoidf(l2[3 * C + c] + cz_bf16_to_f32(L.v0[c]));
         const float dl = v_first[(size_t)b * C + c] - v;
         v = v + dl * nu;
     }
     const float kk0 = kraw * cz_bf16_to_f32(L.k_k[c]);
-    kk[i] = kk0;
+    tmp[i] = kk0 * kk0;
     __syncthreads();
     float ss = 0.0f;
-    for (int j = 0; j < 64; ++j) { const float q = kk[j] * kk[j]; ss = ss + q; }
+#pragma unroll 16
+    for (int j = 0; j < 64; ++j) ss = ss + tmp[j];
     float nrm = sqrtf(ss);
     if (!(nrm > 1e-12f)) nrm = 1e-12f;
     const float kkn = kk0 / nrm;
     const float sc = 1.0f + (a - 1.0f) * cz_bf16_to_f32(L.k_a[c]);
     const float k = kraw * sc;
     __syncthreads();
-    kk[i] = kkn; av[i] = a; kv[i] = k; wv[i] = w; rv[i] = r; vv[i] = v;
+    bc[0][i] = kkn; bc[1][i] = kkn * a; bc[2][i] = w; bc[3][i] = k; bc[4][i] = r;
+    tmp[i] = r * k * cz_bf16_to_f32(L.r_k[c]);                       // the bonus term's r . (k r_k), element i
     __syncthreads();
-    float al = 0.0f;                                                                          // the bonus term's r . (k r_k) does not depend on the state: here, under the state load
-    for (int j = 0; j < 64; ++j) { const float q = rv[j] * kv[j] * cz_bf16_to_f32(L.r_k[h * 64 + j]); al = al + q; }
+    float al = 0.0f;
+#pragma unroll 16
+    for (int j = 0; j < 64; ++j) al = al + tmp[j];
     float t = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 64; ++j) t = cz_fma(srow[j], kk[j], t);                           // (S @ kk)[i]
+    for (int j = 0; j < 64; ++j) t = cz_fma(srow[j], bc[0][j], t);                          // (S @ kk)[i]
     float y = 0.0f;
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
-        const float kka = kk[j] * av[j];
-        const float sn = (srow[j] * wv[j] - t * kka) + v * kv[j];
+        const float sn = (srow[j] * bc[2][j] - t * bc[1][j]) + v * bc[3][j];
         srow[j] = sn;
-        y = cz_fma(sn, rv[j], y);                                                         // (S' @ r)[i]
+        y = cz_fma(sn, bc[4][j], y);                                                        // (S' @ r)[i]
     }
-    if (!mask || mask[b]) {
 #pragma unroll
-        for (int j4 = 0; j4 < 16; ++j4) *reinterpret_cast<float4*>(Srow + 256 * j4) = make_float4(srow[4 * j4], srow[4 * j4 + 1], srow[4 * j4 + 2], srow[4 * j4 + 3]);
-    }
-    yv[i] = y;
+    for (int j4 = 0; j4 < 16; ++j4) *reinterpret_cast<float4*>(Srow + 256 * j4) = make_float4(srow[4 * j4], srow[4 * j4 + 1], srow[4 * j4 + 2], srow[4 * j4 + 3]);
+    __syncthreads();
+    tmp[i] = y;
     __syncthreads();
     float s1 = 0.0f;
-    for (int j = 0; j < 64; ++j) s1 = s1 + yv[j];
+#pragma unroll 16
+    for (int j = 0; j < 64; ++j) s1 = s1 + tmp[j];
     const float mean = s1 * 0.015625f;
     const float cen = y - mean;
     __syncthreads();
-    yv[i] = cen * cen;
+    tmp[i] = cen * cen;
     __syncthreads();
     float s2 = 0.0f;
-    for (int j = 0; j < 64; ++j) s2 = s2 + yv[j];
+#pragma unroll 16
+    for (int j = 0; j < 64; ++j) s2 = s2 + tmp[j];
     const float den = sqrtf(s2 * 0.015625f + (float)64e-5);
     const float gn = cen / den * cz_bf16_to_f32(L.gn_w[c]) + cz_bf16_to_f32(L.gn_b[c]);
     const float ad = al * v;
@@ -490,7 +502,7 @@ static cz_status rw_step_narrow(cz_session* s, int B) {
         }
         s->prof_end(2.0 * B * (double)C * (pw + pa + pg + (y.has_v ? pv : 0)), 2.0 * C * (pw + pa + pg + pv));
         s->prof_begin(PK_RW_STATE);
-        hipLaunchKernelGGL(rw_state_kernel, dim3(B, H), dim3(64), 0, st, m->proj, ldp, L2, y, l, C, S, m->v_first, m->att, m->mask, Bc, 1);
+        hipLaunchKernelGGL(rw_state_kernel, dim3(B, H), dim3(64), (size_t)g_rw_state_pad, st, m->proj, ldp, L2, y, l, C, S, m->v_first, m->att, m->mask, Bc, 1);
         HIPCHK(hipGetLastError());
         s->prof_end(0, st_bytes);
         s->prof_begin(PK_RW_GEMM);
@@ -590,7 +602,7 @@ static cz_status rw_step_wide(cz_session* s, int B) {
         if (y.has_v) HIPCHK(gemm(TV, pv, y.v2_n, L2 + 3 * C, 4 * C, nullptr, C, pv));
         }
         s->prof_begin(PK_RW_STATE);
-        hipLaunchKernelGGL(rw_state_kernel, dim3(B, H), dim3(64), 0, st, m->proj, ldp, L2, y, l, C, S, m->v_first, m->att, m->mask, Bc, 0);
+        hipLaunchKernelGGL(rw_state_kernel, dim3(B, H), dim3(64), (size_t)g_rw_state_pad, st, m->proj, ldp, L2, y, l, C, S, m->v_first, m->att, m->mask, Bc, 0);
         HIPCHK(hipGetLastError());
         s->prof_end(0, st_bytes);
         if (mid) {
@@ -749,7 +761,7 @@ cz_status cz_rwkv7_encode_group(cz_session* s, int B, const uint32_t* const* ids
         for (size_t i = 0; i + 1 < maxn; ++i) {
             if (use_graph) HIPCHK(hipGraphLaunch(m->genc.e, s->stream));
             else CZCHK(iteration((unsigned long long)i, nullptr));
-            if ((i % CZ_SYNC_EVERY) == CZ_SYNC_EVERY - 1) HIPCHK(hipStreamSynchronize(s->stream));
+            if (s->step_sync || (i % CZ_SYNC_EVERY) == CZ_SYNC_EVERY - 1) HIPCHK(hipStreamSynchronize(s->stream));
         }
         std::vector<uint32_t> hlo(npairs), hhi(npairs);
         if (npairs) {
@@ -1124,7 +1136,7 @@ cz_status cz_rwkv7_decode_advance(cz_session* s, size_t n) {
     for (size_t i = run.i; i < stop; ++i) {
         if (run.use_graph) HIPCHK(hipGraphLaunch(m->gdec.e, s->stream));
         else CZCHK(rw_decode_iteration(s, run.B, (unsigned long long)i, nullptr, i + 1 < run.max_tc));
-        if (((i - run.i) % CZ_SYNC_EVERY) == CZ_SYNC_EVERY - 1) HIPCHK(hipStreamSynchronize(s->stream));   // (bounded queue depth: session.hip, decode_llama_advance)
+        if (s->step_sync || ((i - run.i) % CZ_SYNC_EVERY) == CZ_SYNC_EVERY - 1) HIPCHK(hipStreamSynchronize(s->stream));   // (bounded queue depth: session.hip, decode_llama_advance)
     }
     run.i = stop;
     HIPCHK(hipStreamSynchronize(s->stream));

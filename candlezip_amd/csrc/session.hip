@@ -36,6 +36,7 @@ extern int g_dec_attn_lds_pad;
 extern int g_dec_wide_rows;
 extern int g_dec_attn_small_grid;
 extern int g_rw_seq_rows;
+extern int g_rw_state_pad;
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t _e = (expr);                                                                        \
@@ -1030,10 +1031,10 @@ static cz_status decode_llama_advance(cz_session* s, size_t n) {
             }
             if (s->step_sync) HIPCHK(hipStreamSynchronize(s->stream));    // never more than one step of launches queued (profiler runs)
         }
-        // Bound what is queued behind the host: a token is ~160 kernel packets, and thousands of tokens enqueued without a host
+        // Bound what is queued behind the host: a token is 110-220 kernel packets, and thousands of them enqueued without a host
         // synchronisation let the AQL ring back up when something serialises the dispatches — rocprofv3's counter collection does, and its
-        // write-interceptor then runs past the ring's end (SIGSEGV in librocprofiler-sdk).  One wait every CZ_SYNC_EVERY tokens
-        // (<= ~10 k packets in flight, far below the ring) costs one launch latency per ~100 ms of work.
+        // write-interceptor then runs past the ring's end (SIGSEGV in librocprofiler-sdk, DESIGN.md §9: seen at ~8 k packets in flight, not
+        // at ~1.3 k).  One wait every CZ_SYNC_EVERY tokens costs one launch latency per 8 steps (< 0.3 % even for a single stream).
         if (((i - run.i) % CZ_SYNC_EVERY) == CZ_SYNC_EVERY - 1) HIPCHK(hipStreamSynchronize(s->stream));
         index_pos += 1;
     }
@@ -1503,6 +1504,7 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "rwkv_seq")) s->rwkv_seq = (int)value;
     else if (!strcmp(key, "rwkv_wide_min")) s->rwkv_wide_min = (int)value;
     else if (!strcmp(key, "rwkv_wide_mode")) s->rwkv_wide_mode = (int)value;
+    else if (!strcmp(key, "rw_state_pad")) g_rw_state_pad = (int)value < 0 ? 0 : ((int)value > 48000 ? 48000 : (int)value);
     else if (!strcmp(key, "rwkv_seq_rows")) g_rw_seq_rows = (int)value < 1 ? 1 : (int)value;
     else if (!strcmp(key, "mid_nw")) g_mid_nw = (int)value;
     else if (!strcmp(key, "mid_colmaj")) g_mid_colmaj = (int)value;
