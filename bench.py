@@ -85,14 +85,14 @@ def rocprof_avg_us(prefix, tokens):
     """average kernel duration of a kernel function from the committed rocprofv3 --kernel-trace --stats summary of the pass this script
     measures its rooflines on (profiles/r*_pass<tokens>_*kernel_stats.csv, tools/prof_summary.py; newest round first).  The HIP-event figure
     next to it brackets launch + kernel + the gap to the next event record, so it reads a few us longer per launch."""
-    import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pass{tokens}_*kernel_stats.csv")), reverse=True)
     for f in files:
         calls = 0; tot = 0.0
-        for r in csv.DictReader(open(f)):
-            if r["kernel"].startswith(prefix):
-                calls += int(r["calls"]); tot += float(r["total_ms"])
+        for line in open(f).read().splitlines()[1:]:             # kernel names hold commas (template arguments): the six numbers are the LAST six fields
+            parts = line.rsplit(",", 6)
+            if len(parts) == 7 and parts[0].startswith(prefix):
+                calls += int(parts[1]); tot += float(parts[2])
         if calls:
             return round(1e3 * tot / calls, 3), os.path.basename(f)
     return None, None
@@ -474,7 +474,7 @@ def main_rwkv7(args):
             "compress_tokens_per_s_rank0": round(tok / te, 1) if te else None, "decompress_tokens_per_s_rank0": round(tok / td, 1) if td else None,
             "roofline": roof("rwkv7_state", "hbm", "rw_state_kernel", "rw_state_kernel (decode: WKV state update of one token per stream)"),
             "roofline_scan": roof("rwkv7_scan", "hbm", "rw_seq_scan_kernel", "rw_seq_scan_kernel (encode: WKV scan over a time block, state in registers)"),
-            "roofline_rwkv_gemm_decode": roof("rwkv7_gemm", "mfma", "gemm_bf16w_kernel", "projections of the decode step"),
+            "roofline_rwkv_gemm_decode": roof("rwkv7_gemm", "mfma", "gemm_mid_", "gemm_mid_kernel / gemm_mid_group_kernel (projections of the wide decode step)"),
             "roofline_mfma_gemm": roof("gemm_bf16w_f32_mfma", "mfma", "gemm_bf16w_kernel<128, 128", "gemm_bf16w_kernel (encode projections, lm_head)"),
             "families_ms_profile_pass": {k: round(v["total_ms"], 2) for k, v in prof.items()},
         }
