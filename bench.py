@@ -345,7 +345,7 @@ def cpu_baseline_rwkv7(sample_tokens):
 
 def main_rwkv7(args):
     """BASELINE configs[3]: `--backend rwkv7` on Canterbury-sized inputs, 1 GPU, recurrent-state kernel path.  One step = the self-test of a fresh
-    batch: `--streams` streams (64 KiB chunks of the corpus) x `--sample-tokens` tokens each — compress (sequence-parallel: every token of a time
+    batch: `--streams` streams (chunks of the corpus) x `--sample-tokens` tokens each — compress (sequence-parallel: every token of a time
     block through the projections at once, only the WKV scan sequential in t) + the serial coder + decompress (lock-step groups on decode lanes) —
     round trip verified every step.  RWKV has no re-prime: a stream's state starts at zero, like a file's.  Weights / ids synthetic (no
     checkpoint, vocabulary or corpus offline): bits/byte is null."""
@@ -420,7 +420,7 @@ def main_rwkv7(args):
     if args.profile_tokens > 0:
         pt = min(args.profile_tokens, T)
         rng = np.random.default_rng(99)
-        short = [np.concatenate([[0], rng.integers(0, cfg.vocab, pt)]).astype(np.uint32) for _ in range(min(per_lane, S))]
+        short = [np.concatenate([[0], rng.integers(0, cfg.vocab, pt)]).astype(np.uint32) for _ in range(min(per_lane, S, 256))]       # (256 streams: the pass profiles/r03_passrwkv7_s256_t512_* were taken on)
         sess.debug_set("no_graph", 1)
         sess.profile_enable(True)
         pairs = sess.encode_tokens_batch(short)
@@ -456,7 +456,7 @@ def main_rwkv7(args):
             r.update({"traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": tnote, "kernel": kernel, "family": fam,
                       "algorithmic_per_launch": round((st["flops"] if bound == "mfma" else st["bytes"]) / n), "algorithmic_unit": "flop" if bound == "mfma" else "bytes",
                       "launches": st["launches"], "avg_launch_us": round(1e3 * ms / n, 3), "avg_kernel_us_rocprof": rp_us, "avg_kernel_us_rocprof_source": rp_src,
-                      "total_ms": round(ms, 2), "measured_in": f"eager per-family pass inside bench.py ({min(per_lane, S)} streams x {min(args.profile_tokens, T)} tokens, one lane)"})
+                      "total_ms": round(ms, 2), "measured_in": f"eager per-family pass inside bench.py ({min(per_lane, S, 256)} streams x {min(args.profile_tokens, T)} tokens, one lane)"})
             if rp_us:
                 alg = (st["flops"] if bound == "mfma" else st["bytes"]) / n
                 r["achieved_rocprof"] = round(alg / (rp_us * 1e-6) / (1e12 if bound == "mfma" else 1e9), 3)
@@ -514,9 +514,10 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="tiny model (plumbing check only)")
     args = ap.parse_args()
     # defaults per backend: smollm = 1024 persistent streams x 17 408 tokens in 2 lock-step groups of 512, 17 window steps;
-    # rwkv7 = 512 streams x 4096 tokens per step in 2 groups of 256, 3 steps
+    # rwkv7 = 1024 streams x 2048 tokens per step in ONE lock-step group (the wide step's GEMMs fill the device best at 1024 rows: 179 k tokens/s
+    # decompress against 168 k for 2 x 256, profiles/r03_rwkv7_lane_shapes_final.jsonl), 3 steps
     dflt = {"smollm": dict(steps=17, streams=1024, lanes=2, lane_streams=512, sample_tokens=17408, profile_tokens=2048),
-            "rwkv7": dict(steps=3, streams=512, lanes=2, lane_streams=256, sample_tokens=4096, profile_tokens=512)}[args.backend]
+            "rwkv7": dict(steps=3, streams=1024, lanes=1, lane_streams=1024, sample_tokens=2048, profile_tokens=512)}[args.backend]
     for k, v in dflt.items():
         if getattr(args, k) is None:
             setattr(args, k, v)

@@ -187,3 +187,49 @@ extern "C" cz_status cz_debug_attention(const float* Q, const float* K, const fl
 fail:
     return CZ_ERR_HIP;
 }
+
+// ---- measurement aid (tools/probe_chain.py): the cost of one node in a chain of dependent kernels, as the decode step of a single stream is one.
+// kind 0: one lane adds 1 to a word (nothing but the dependency); kind 1: `blocks` blocks of 256 threads each stream `kb` KB of a buffer and one
+// lane per block adds its sum to a word (a weight-streaming GEMV's memory shape without its arithmetic).
+__global__ void probe_chain_kernel(float* acc, const float* __restrict__ buf, int kb) {
+    float s = 0.0f;
+    if (kb > 0) {
+        const float4* p = reinterpret_cast<const float4*>(buf) + (size_t)blockIdx.x * (kb * 64) + threadIdx.x;
+        for (int i = 0; i < kb * 64 / 256; ++i) { const float4 v = p[i * 256]; s += v.x + v.y + v.z + v.w; }
+    }
+    if (threadIdx.x == 0) acc[blockIdx.x] = acc[blockIdx.x] + 1.0f + s * 0.0f;
+}
+extern "C" cz_status cz_debug_probe_chain(int nodes, int blocks, int kb, int iters, int use_graph, double* us_per_node) {
+    DevMem m;
+    float* acc = (float*)m.alloc((size_t)(blocks > 0 ? blocks : 1) * 4);
+    const size_t bytes = (size_t)(blocks > 0 ? blocks : 1) * (kb > 0 ? kb : 1) * 1024;
+    float* buf = (float*)m.alloc(bytes);
+    if (!acc || !buf || nodes <= 0 || iters <= 0 || blocks <= 0 || (kb && kb % 4)) { cz_set_error("cz_debug_probe_chain: bad argument"); return CZ_ERR_ARG; }
+    hipStream_t st = nullptr; hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0.0f;
+    PCHK(hipMemset(acc, 0, (size_t)blocks * 4)); PCHK(hipMemset(buf, 0, bytes));
+    PCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    PCHK(hipEventCreate(&e0)); PCHK(hipEventCreate(&e1));
+    if (use_graph) {
+        PCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        for (int n = 0; n < nodes; ++n) hipLaunchKernelGGL(probe_chain_kernel, dim3(blocks), dim3(256), 0, st, acc, buf, kb);
+        PCHK(hipStreamEndCapture(st, &g));
+        PCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        PCHK(hipGraphLaunch(ge, st)); PCHK(hipStreamSynchronize(st));
+    }
+    PCHK(hipEventRecord(e0, st));
+    for (int it = 0; it < iters; ++it) {
+        if (use_graph) PCHK(hipGraphLaunch(ge, st));
+        else for (int n = 0; n < nodes; ++n) hipLaunchKernelGGL(probe_chain_kernel, dim3(blocks), dim3(256), 0, st, acc, buf, kb);
+    }
+    PCHK(hipEventRecord(e1, st));
+    PCHK(hipStreamSynchronize(st));
+    PCHK(hipEventElapsedTime(&ms, e0, e1));
+    *us_per_node = 1e3 * ms / ((double)iters * nodes);
+    if (ge) hipGraphExecDestroy(ge);
+    if (g) hipGraphDestroy(g);
+    hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(st);
+    return CZ_OK;
+fail:
+    return CZ_ERR_HIP;
+}

@@ -128,3 +128,23 @@ def test_corpus_self_test_on_reference_inputs():
     assert r.returncode == 0, r.stderr + r.stdout
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["roundtrip_failures"] == [] and d["chunks"] == 10 + 8 + 8 + 1 and d["tokens"] > 100000 and d["self_test_tokens_per_s"] > 0
+
+
+@pytest.mark.gpu
+def test_reprime_interval_beyond_2048_positions_and_the_model_limit(tmp_path):
+    """`--reprime-interval` is bounded by the model only (src/main.rs:1935, 2280-2284, 2506): 2 600 tokens at interval 2 000 reach 2 511 positions
+    (SmolLM2-135M shape, max_position_embeddings 8192) and round-trip through the CLI; an interval whose schedule would pass 8192 positions is
+    refused before anything runs, where the reference would fail in the middle of the file"""
+    ids = np.random.default_rng(3).integers(0, 49152, 2600).astype("<u4")
+    idf = tmp_path / "tok.ids"; ids.tofile(idf)
+    inp = tmp_path / "in.txt"; inp.write_bytes(b"z" * 5000)
+    out = tmp_path / "o.canz"; back = tmp_path / "back.ids"
+    r = _run("--synthetic", "1", "--token-ids", str(idf), "--reprime-interval", "2000", "compress", str(inp), str(out))
+    assert r.returncode == 0 and "bits/byte=" in r.stdout, r.stderr
+    r = _run("--synthetic", "1", "--token-ids", str(idf), "decompress", str(out), str(back))
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.fromfile(back, "<u4"), ids)
+    big = np.random.default_rng(4).integers(0, 49152, 16500).astype("<u4")
+    bigf = tmp_path / "big.ids"; big.tofile(bigf)
+    r = _run("--synthetic", "1", "--token-ids", str(bigf), "--reprime-interval", "8000", "compress", str(inp), str(tmp_path / "no.canz"))
+    assert r.returncode != 0 and "max_position_embeddings" in r.stderr, r.stderr[-500:]
