@@ -19,6 +19,23 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// tuning build (make dec_dbg, tools/dec_phases.py): block (0, 0) / thread 0 accumulates s_memrealtime ticks (10 ns) per phase of the narrow-group
+// kernels; every stamp first waits for the wave's outstanding memory operations, so a phase includes the latency of what it requested
+#ifdef CZ_DEC_STAMPS
+__device__ unsigned long long g_dec_stamp[8][16];
+#define DST_BEGIN unsigned long long st_t = 0; if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) st_t = wall_clock64()
+#define DST(kind, ph) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = wall_clock64(); \
+                                atomicAdd(&g_dec_stamp[kind][ph], t_ - st_t); if ((ph) == 15) atomicAdd(&g_dec_stamp[kind][0], 1ull); st_t = t_; } } while (0)
+extern "C" void cz_debug_dec_stamps(unsigned long long* out128, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_dec_stamp), sizeof(unsigned long long) * 128);
+    if (reset) { unsigned long long z[128] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_dec_stamp), z, sizeof z); }
+}
+#else
+#define DST_BEGIN do { } while (0)
+#define DST(kind, ph) do { } while (0)
+#endif
+
 __host__ __device__ __forceinline__ int kq_index(int k) { return (k & ~63) | ((k & 3) << 4) | ((k & 63) >> 2); }
 
 // Wd[n][kq(k)] = W[n][k]
@@ -113,6 +130,7 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
         }
     }
     const int K = a.K, nch = K >> 6;
+    DST_BEGIN;
     // A narrow group's kernel is a chain of dependent memory round trips (HBM-cold weights ~2 us each), not of arithmetic: everything that
     // does not depend on a result is requested HERE, before the norm phase and its barrier — the first round's weight slab, the plain A
     // operand (PFA: where its registers are affordable), the step position and the rotation's cos / sin (epilogue) — so that the chain is one
@@ -151,6 +169,13 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
             apf2[m][0] = ap[0]; apf2[m][1] = ap[1]; apf2[m][2] = ap[2]; apf2[m][3] = ap[3];
         }
     }
+    constexpr bool PFN = HOIST && NORM == 2;                     // the RMSNorm weights of the wave's chunk (16 bf16 per lane) as well: they sat behind the norm phase's barrier
+    float nw_pf[PFN ? 16 : 1];
+    if (PFN && wave < nch) {
+        const uint16_t* wr = a.normw + wave * 64 + lg;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) nw_pf[PFN ? t : 0] = cz_bf16_to_f32(wr[4 * t]);
+    }
     int pos_pf = 0; float c_pf[NP], s_pf[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) { c_pf[p] = 0.0f; s_pf[p] = 0.0f; }
@@ -160,6 +185,7 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
         for (int p = 0; p < NP; ++p)
             if ((n0[p] >> 6) < a.n_heads + a.n_kv) { const int i = (n0[p] & 63) + (tid & 15); c_pf[p] = a.cs[(size_t)pos_pf * 32 + i]; s_pf[p] = a.sn[(size_t)pos_pf * 32 + i]; }
     }
+    DST(EPI + 4 * (NORM ? 1 : 0), 1);          // the hoisted operands have arrived
     // NORM == 2 (single round: nch <= NW, MT <= 2): the wave that owns chunk c reads x[rows][chunk c] once, for the sum of squares AND as
     // its A operand.  The canonical chunk sum p = p + x_k * x_k (product rounded, then added, k ascending) is an MFMA chain with B = 1:
     // fma(x_k^2, 1, p) rounds x_k^2 + p once, exactly like the add.  No separate pass over the rows, no serial 64-long chains.
@@ -216,6 +242,7 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
         }
         __syncthreads();
     }
+    DST(EPI + 4 * (NORM ? 1 : 0), 2);          // norm phase done
     float tot0[NP][MT], tot1[NP][MT];            // element (r = tid >> 4, c = tid & 15) of both column tiles of pair p, row tile m; threads 0..255
     float res0[NP][MT], res1[NP][MT];            // residual, fetched now so that its latency hides under the weight loads + MFMA chain
 #pragma unroll
@@ -245,7 +272,10 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
             for (int m = 0; m < MT; ++m) {
                 const int arow = min(m0 + m * 16 + li, a.M - 1);                  // (clamped: no branch between the row tiles' loads)
                 f32x4 av[4];
-                if (NORM == 2) {
+                if (NORM == 2 && PFN) {
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) av[t >> 2][t & 3] = xv[m][t] / mv2[m] * nw_pf[PFN ? t : 0];
+                } else if (NORM == 2) {
                     const uint16_t* wr = a.normw + c * 64 + lg;
 #pragma unroll
                     for (int t = 0; t < 16; ++t) av[t >> 2][t & 3] = xv[m][t] / mv2[m] * cz_bf16_to_f32(wr[4 * t]);
@@ -278,6 +308,7 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
                 }
             }
         }
+        DST(EPI + 4 * (NORM ? 1 : 0), 3);      // MFMA chains of the round
         // ordered reduction of the chunk partials, G row tiles per round
 #pragma unroll
         for (int mg = 0; mg < MT; mg += G) {
@@ -309,6 +340,7 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
             }
             __syncthreads();
         }
+        DST(EPI + 4 * (NORM ? 1 : 0), 4);      // ordered reduction of the round
     }
     if (tid >= 256) return;
     const int r = tid >> 4, cc = tid & 15;
@@ -354,6 +386,7 @@ __device__ __forceinline__ void dec_gemm_body(const dec_gemm_args& a, const int 
             }
         }
     }
+    DST(EPI + 4 * (NORM ? 1 : 0), 15);         // epilogue
 }
 
 template <int EPI, int NORM, int MT, int NP>
@@ -545,8 +578,10 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : 4)) void dec_attn
     float* red = part + (LONG ? DA_WAVES : nch_max) * rep * 64;             // [DA_WAVES][DA_MAXREP] local maxima
     float* csum = red + DA_MAXW * DA_MAXREP;            // [rep][CS]       chunk sums of e
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    DST_BEGIN;
     if (tid < rep * 64) qs[tid] = Q[(size_t)sd.row0 * ldq + (qh0 + (tid >> 6)) * 64 + (tid & 63)];
     __syncthreads();
+    DST(3, 1);                                  // descriptor, position, Q in LDS
     // ---- phase 1: scores of the wave's chunks (lane = key), kept in registers
     float sc[DA_MAXC][DA_MAXREP];
     float lm[DA_MAXREP] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -601,11 +636,25 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : 4)) void dec_attn
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const float y = __shfl_xor(lm[h], o); lm[h] = y > lm[h] ? y : lm[h]; }
     }
+    DST(3, 2);                                  // phase 1: K streamed, scores
+    // DEEP: the V slab of the wave's first chunk is requested NOW — the K registers are free — and arrives under the two softmax phases and their
+    // barriers (the bit pattern of what is loaded does not depend on them); phase 3 then starts on resident data
+    float vpre[DEEP ? 64 : 1];
+    if (DEEP) {
+        const int c = wave;
+        if (c < nch) {
+            const int jend = nk - c * 64 < 64 ? nk - c * 64 : 64;
+            gfloat* vp = Vb + (size_t)(c * 64) * sd.kv_stride + lane;
+#pragma unroll
+            for (int jx = 0; jx < 64; ++jx) { const int jj = jx < jend ? jx : jend - 1; vpre[DEEP ? jx : 0] = __builtin_nontemporal_load(vp + (size_t)jj * sd.kv_stride); }
+        }
+    }
     if (lane == 0) {
 #pragma unroll
         for (int h = 0; h < DA_MAXREP; ++h) red[wave * DA_MAXREP + h] = lm[h];
     }
     __syncthreads();
+    DST(3, 3);                                  // barrier after the local maxima
     // ---- phase 2: e = exp(s - max), chunk sums in the canonical order (one lane per head walks the 64 values)
     float gm[DA_MAXREP];
 #pragma unroll
@@ -638,6 +687,7 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : 4)) void dec_attn
         }
     }
     __syncthreads();
+    DST(3, 4);                                  // phase 2: exp, chunk sums, barrier
     // ---- phase 3: total (chunks left to right), p = e / total, P.V chunk partials (lane = d, keys ascending)
     float tot[DA_MAXREP];
 #pragma unroll
@@ -670,8 +720,13 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : 4)) void dec_attn
             // for each one.  Keys past nk have p == 0 (exp(-inf)) and v == 0: fma(0, 0, acc) == acc, so the chain needs no guard.
             auto v_round = [&](const int g) {
                 float vreg[16];
+                if (DEEP && i == 0) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) { const int jx = g * 16 + j; const int jj = jx < jend ? jx : jend - 1; vreg[j] = __builtin_nontemporal_load(vp + (size_t)jj * sd.kv_stride); }
+                    for (int j = 0; j < 16; ++j) vreg[j] = vpre[DEEP ? g * 16 + j : 0];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { const int jx = g * 16 + j; const int jj = jx < jend ? jx : jend - 1; vreg[j] = __builtin_nontemporal_load(vp + (size_t)jj * sd.kv_stride); }
+                }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) vreg[j] = g * 16 + j < jend ? vreg[j] : 0.0f;
 #pragma unroll
@@ -705,6 +760,7 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : 4)) void dec_attn
             __syncthreads();
         }
     }
+    DST(3, 5);                                  // phase 3: V streamed, P.V partials
     if (!LONG) __syncthreads();
     if (tid < rep * 64) {
         const int h = tid >> 6, dd = tid & 63;
@@ -716,6 +772,7 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : 4)) void dec_attn
         const int col = (qh0 + h) * 64 + dd;
         O[(size_t)sd.row0 * ldo + (out_kq ? kq_index(col) : col)] = t;          // kq layout feeds dec_gemm_kernel's o-projection, natural layout the tiled GEMM
     }
+    DST(3, 15);                                 // ordered sum of the partials, output
 }
 #define DA_LONG_W 16
 #define DA_LONG_C 8                                   // 16 waves x 8 chunks x 64 keys = 8192 positions
