@@ -91,6 +91,7 @@ struct cz_session {
     int* pos_dev = nullptr;
     cz_seq_desc* step_seqd = nullptr; cz_rope_desc* step_roped = nullptr; int* step_rows = nullptr;
     float* step_logits = nullptr; uint32_t* step_sym = nullptr;
+    float* attn_split = nullptr; int attn_split_streams = 0;      // scratch of the three-launch decode attention of small groups (cz_launch_dec_attn)
     size_t index_pos = 0;              // SmolLmSession::index_pos (src/models.rs:65)
     DecRun run;                        // this lane's group of a sliced decode
     std::vector<size_t> run_off;       // parent only: group g of the sliced decode = streams [run_off[g], run_off[g+1]) on lane g

@@ -774,6 +774,118 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : 4)) void dec_attn
     }
     DST(3, 15);                                 // ordered sum of the partials, output
 }
+// ------------------------------------------------------------------------------------------------------------
+// Split decode attention for a HANDFUL of streams (nstreams x n_heads <= dec_attn_split_max blocks of the one-kernel form).  There a query head's
+// block streams its whole K and V alone on one CU — 393 KB at 767 keys, i.e. at the ~65 GB/s ONE CU streams at, 6 of the kernel's 13 us
+// (profiles/r03_dec_phases_b1.json).  Spread over (head, 64-key chunk) blocks the same bytes move on 12x as many CUs.  The exact softmax needs the
+// maximum over ALL keys before any exponential, so this is three dependent launches instead of one (2-3 us each):
+//   da_split_scores_kernel : block = (stream, q head, chunk): the chunk's 64 scores (the same d-ascending fmaf chain) and its maximum
+//   da_split_pv_kernel     : block = (stream, q head, chunk): global max of the head's chunk maxima; e = exp(s - max) of EVERY chunk (3 KB of
+//                            scores: cheap to redo per block), the canonical chunk sums (lane c walks chunk c), total left to right,
+//                            p = e / total of the own chunk, P.V partial of the own chunk (lane = d, keys ascending)
+//   da_split_sum_kernel    : block = (stream, q head): the chunk partials added left to right -> O
+// Arithmetic and order are dec_attn_kernel's, statement for statement: the same bits.
+#define DA_SPLIT_MAXC 32                               // chunks of 64 keys: contexts up to 2048
+__global__ __launch_bounds__(64) void da_split_scores_kernel(const float* __restrict__ Q, int ldq, const cz_seq_desc* __restrict__ descs, int n_heads, int rep,
+                                                             size_t kv_off, const int* __restrict__ pos_dev, float* __restrict__ SC /*[S][H][2048]*/,
+                                                             float* __restrict__ CM /*[S][H][32]*/) {
+    __shared__ __attribute__((aligned(16))) float qs[64];
+    cz_seq_desc sd = descs[blockIdx.x];
+    const int pos = pos_dev ? *pos_dev : sd.pos0;
+    const int nk = pos + 1, c = blockIdx.z, h = blockIdx.y, lane = threadIdx.x;
+    if (c * 64 >= nk) return;
+    const int kvh = h / rep;
+    gfloat* Kb = (gfloat*)(sd.k + kv_off + (sd.kt_stride ? (size_t)kvh * 64 * sd.kt_stride : (size_t)kvh * 64));
+    const int j = c * 64 + lane, jc = j < nk ? j : nk - 1;                       // (clamped address, the value is discarded below)
+    float kreg[64];
+    if (sd.kt_stride) {
+#pragma unroll
+        for (int d = 0; d < 64; ++d) kreg[d] = __builtin_nontemporal_load(Kb + (size_t)d * sd.kt_stride + jc);
+    } else {
+        const __attribute__((address_space(1))) f32x4* kr = (const __attribute__((address_space(1))) f32x4*)(Kb + (size_t)jc * sd.kv_stride);
+#pragma unroll
+        for (int q4 = 0; q4 < 16; ++q4) { const f32x4 t4 = kr[q4]; kreg[4 * q4] = t4[0]; kreg[4 * q4 + 1] = t4[1]; kreg[4 * q4 + 2] = t4[2]; kreg[4 * q4 + 3] = t4[3]; }
+    }
+    qs[lane] = Q[(size_t)sd.row0 * ldq + h * 64 + lane];
+    __syncthreads();
+    float sacc = 0.0f;
+#pragma unroll
+    for (int q4 = 0; q4 < 16; ++q4) {
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + q4 * 4);
+        sacc = cz_fma(qv[0], kreg[4 * q4], sacc); sacc = cz_fma(qv[1], kreg[4 * q4 + 1], sacc);
+        sacc = cz_fma(qv[2], kreg[4 * q4 + 2], sacc); sacc = cz_fma(qv[3], kreg[4 * q4 + 3], sacc);
+    }
+    const float sc = j < nk ? sacc * 0.125f : -INFINITY;
+    const size_t hb = (size_t)blockIdx.x * n_heads + h;
+    SC[hb * (DA_SPLIT_MAXC * 64) + c * 64 + lane] = sc;
+    float m = sc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float y = __shfl_xor(m, o); m = y > m ? y : m; }
+    if (lane == 0) CM[hb * DA_SPLIT_MAXC + c] = m;
+}
+__global__ __launch_bounds__(64) void da_split_pv_kernel(const cz_seq_desc* __restrict__ descs, int n_heads, int rep, size_t kv_off, const int* __restrict__ pos_dev,
+                                                         const float* __restrict__ SC, const float* __restrict__ CM, float* __restrict__ PART /*[S][H][32][64]*/) {
+    __shared__ __attribute__((aligned(16))) float E[DA_SPLIT_MAXC][64];
+    __shared__ float csum[DA_SPLIT_MAXC];
+    cz_seq_desc sd = descs[blockIdx.x];
+    const int pos = pos_dev ? *pos_dev : sd.pos0;
+    const int nk = pos + 1, nch = (nk + 63) >> 6, c = blockIdx.z, h = blockIdx.y, lane = threadIdx.x;
+    if (c >= nch) return;
+    const int kvh = h / rep;
+    gfloat* Vb = (gfloat*)(sd.v + kv_off + kvh * 64);
+    const size_t hb = (size_t)blockIdx.x * n_heads + h;
+    // the V slab of this chunk first (lane = d, 64 keys): it is in flight under the softmax statistics below
+    const int jend = nk - c * 64 < 64 ? nk - c * 64 : 64;
+    gfloat* vp = Vb + (size_t)(c * 64) * sd.kv_stride + lane;
+    float vreg[64];
+#pragma unroll
+    for (int jx = 0; jx < 64; ++jx) { const int jj = jx < jend ? jx : jend - 1; vreg[jx] = __builtin_nontemporal_load(vp + (size_t)jj * sd.kv_stride); }
+    // global maximum (exact in any order)
+    float m = lane < nch ? CM[hb * DA_SPLIT_MAXC + lane] : -INFINITY;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float y = __shfl_xor(m, o); m = y > m ? y : m; }
+    const float* sc = SC + hb * (DA_SPLIT_MAXC * 64);
+    float mine = 0.0f;
+    for (int cc = 0; cc < nch; ++cc) {
+        const float e = cz_expf(sc[cc * 64 + lane] - m);
+        E[cc][lane] = e;
+        if (cc == c) mine = e;
+    }
+    __syncthreads();
+    if (lane < nch) {                                                            // canonical chunk sum: acc = acc + e_k, k ascending from +0
+        float acc = 0.0f;
+#pragma unroll 16
+        for (int k = 0; k < 64; ++k) acc = acc + E[lane][k];
+        csum[lane] = acc;
+    }
+    __syncthreads();
+    float tot = csum[0];
+    for (int cc = 1; cc < nch; ++cc) tot = tot + csum[cc];
+    __syncthreads();
+    E[0][lane] = mine / tot;                                                     // p of the own chunk (E[0] is free: every lane has read what it needs)
+    __syncthreads();
+    float acc = 0.0f;
+#pragma unroll
+    for (int jx = 0; jx < 64; ++jx) acc = cz_fma(E[0][jx], jx < jend ? vreg[jx] : 0.0f, acc);
+    PART[(hb * DA_SPLIT_MAXC + c) * 64 + lane] = acc;
+}
+__global__ __launch_bounds__(64) void da_split_sum_kernel(const cz_seq_desc* __restrict__ descs, int n_heads, const int* __restrict__ pos_dev, const float* __restrict__ PART,
+                                                          float* __restrict__ O, int ldo, int out_kq) {
+    const cz_seq_desc sd = descs[blockIdx.x];
+    const int pos = pos_dev ? *pos_dev : sd.pos0;
+    const int nch = (pos + 1 + 63) >> 6, h = blockIdx.y, d = threadIdx.x;
+    const float* pp = PART + ((size_t)blockIdx.x * n_heads + h) * DA_SPLIT_MAXC * 64 + d;
+    float v[DA_SPLIT_MAXC];
+#pragma unroll
+    for (int c = 0; c < DA_SPLIT_MAXC; ++c) v[c] = pp[(size_t)(c < nch ? c : nch - 1) * 64];          // (all loads in flight; the clamp keeps them in bounds)
+    float t = v[0];
+#pragma unroll
+    for (int c = 1; c < DA_SPLIT_MAXC; ++c) if (c < nch) t = t + v[c];
+    const int col = h * 64 + d;
+    O[(size_t)sd.row0 * ldo + (out_kq ? kq_index(col) : col)] = t;
+}
+size_t cz_dec_attn_split_bytes(int nstreams, int n_heads) { return (size_t)nstreams * n_heads * ((size_t)DA_SPLIT_MAXC * 64 + DA_SPLIT_MAXC + (size_t)DA_SPLIT_MAXC * 64) * sizeof(float); }
+int g_dec_attn_split_max = 128;     // tuning knob (cz_debug_set "dec_attn_split_max"): groups with nstreams x n_heads <= this take the three-launch form (0 = never)
 #define DA_LONG_W 16
 #define DA_LONG_C 8                                   // 16 waves x 8 chunks x 64 keys = 8192 positions
 static int da_s_stride(int max_nk) { return ((max_nk + 63) / 64) * 64 + 4; }
@@ -825,10 +937,20 @@ static void da_launch(hipStream_t st, int rep, dim3 grid, size_t smem, const flo
 int g_dec_attn_lds_pad = 0;         // tuning knob (cz_debug_set "dec_attn_lds_pad"): extra dynamic LDS bytes per block of the whole-device grids (fewer blocks per CU)
 int g_dec_attn_split_heads = 1;     // tuning knob (cz_debug_set "dec_attn_split_heads"): 0 = never one block per query head
 hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nstreams, int max_nk,
-                              int n_heads, int n_kv, size_t kv_off, const int* pos_dev, int out_kq) {
+                              int n_heads, int n_kv, size_t kv_off, const int* pos_dev, int out_kq, float* split_scratch, int split_streams) {
     if (nstreams <= 0) return hipSuccess;
     const int rep = n_heads / n_kv;
     if (rep < 1 || rep > DA_MAXREP || max_nk > CZ_KERNEL_MAX_CTX) return hipErrorInvalidValue;
+    if (split_scratch && nstreams <= split_streams && max_nk <= DA_SPLIT_MAXC * 64 && nstreams * n_heads <= g_dec_attn_split_max) {
+        float* SC = split_scratch;
+        float* CM = SC + (size_t)split_streams * n_heads * DA_SPLIT_MAXC * 64;
+        float* PART = CM + (size_t)split_streams * n_heads * DA_SPLIT_MAXC;
+        const int nchm = (max_nk + 63) / 64;
+        hipLaunchKernelGGL(da_split_scores_kernel, dim3(nstreams, n_heads, nchm), dim3(64), 0, st, Q, ldq, descs, n_heads, rep, kv_off, pos_dev, SC, CM);
+        hipLaunchKernelGGL(da_split_pv_kernel, dim3(nstreams, n_heads, nchm), dim3(64), 0, st, descs, n_heads, rep, kv_off, pos_dev, SC, CM, PART);
+        hipLaunchKernelGGL(da_split_sum_kernel, dim3(nstreams, n_heads), dim3(64), 0, st, descs, n_heads, pos_dev, PART, O, ldo, out_kq);
+        return hipGetLastError();
+    }
     const int ss = da_s_stride(max_nk);
     if (max_nk > 2048) {            // contexts past 2048 keys (a re-prime interval > 1536): the 16-wave variant whose waves walk 8 chunks each
         da_launch<DA_LONG_W, DA_LONG_C>(st, rep, dim3(nstreams, n_kv), da_smem_long(max_nk, rep), Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, 1);

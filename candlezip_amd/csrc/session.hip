@@ -35,6 +35,7 @@ extern int g_dec_attn_split_heads;
 extern int g_dec_attn_lds_pad;
 extern int g_dec_wide_rows;
 extern int g_dec_attn_small_grid;
+extern int g_dec_attn_split_max;
 extern int g_rw_seq_rows;
 extern int g_rw_state_pad;
 #define HIPCHK(expr)                                                                                   \
@@ -445,6 +446,8 @@ static cz_status ensure_streams(cz_session* s, int B, size_t need_ctx = 0, bool 
             HIPCHK(hipStreamSynchronize(s->stream));
             HIPCHK(hipMalloc((void**)&s->step_logits, (size_t)s->max_streams * c.vocab * 4));
             HIPCHK(hipMalloc((void**)&s->step_sym, (size_t)s->max_streams * 4));
+            s->attn_split_streams = std::min(s->max_streams, 32);                 // (groups of more streams than that never take the split form)
+            HIPCHK(hipMalloc((void**)&s->attn_split, cz_dec_attn_split_bytes(s->attn_split_streams, c.n_heads)));
         }
     }
     return CZ_OK;
@@ -471,7 +474,7 @@ static cz_status llama_step_fast(cz_session* s, int B, int pos, int max_nk) {
         }
         if (!(s->dbg_skip & 1)) {
         s->prof_begin(PK_DEC_ATTN);
-        HIPCHK(cz_launch_dec_attn(st, q, d, att, d, s->step_seqd, B, max_nk, c.n_heads, c.n_kv_heads, kv_off, s->pos_dev));
+        HIPCHK(cz_launch_dec_attn(st, q, d, att, d, s->step_seqd, B, max_nk, c.n_heads, c.n_kv_heads, kv_off, s->pos_dev, 1, s->attn_split, s->attn_split_streams));
         s->prof_end(4.0 * 64 * c.n_heads * (double)B * (pos + 1), 2.0 * B * (double)(pos + 1) * kvd * 4);
         }
         if (s->dbg_skip & 2) continue;
@@ -539,7 +542,7 @@ static cz_status llama_step_wide(cz_session* s, int B, int pos, int max_nk) {
         }
         if (!(s->dbg_skip & 1)) {
             s->prof_begin(PK_DEC_ATTN);
-            HIPCHK(cz_launch_dec_attn(st, qkv, nq, xn, d, s->step_seqd, B, max_nk, c.n_heads, c.n_kv_heads, kv_off, s->pos_dev, hybrid ? 1 : 0));
+            HIPCHK(cz_launch_dec_attn(st, qkv, nq, xn, d, s->step_seqd, B, max_nk, c.n_heads, c.n_kv_heads, kv_off, s->pos_dev, hybrid ? 1 : 0, s->attn_split, s->attn_split_streams));
             s->prof_end(4.0 * 64 * c.n_heads * (double)B * (pos + 1), 2.0 * B * (double)(pos + 1) * kvd * 4);
         }
         if (s->dbg_skip & 2) continue;
@@ -1107,7 +1110,7 @@ extern "C" void cz_session_close(cz_session* s) {
     for (auto e : s->evt_free) hipEventDestroy(e);
     for (DevBuf* b : s->all_bufs()) b->release();
     void* ptrs[] = {s->cdf_scratch, s->fallback_dev, s->llama.blob_gu, s->llama.blob_k2, s->llama.blob_dec, s->llama.blob, s->llama.rope_cos, s->llama.rope_sin, s->kvcache, s->pos_dev, s->step_seqd, s->step_roped, s->step_rows,
-                    s->step_logits, s->step_sym};
+                    s->step_logits, s->step_sym, s->attn_split};
     for (auto p : ptrs) if (p) { hipError_t e = hipFree(p); (void)e; }
     cz_rwkv7_destroy(s);
     if (s->stream) hipStreamDestroy(s->stream);
@@ -1512,6 +1515,7 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "dec_attn_lds_pad")) g_dec_attn_lds_pad = (int)value;              // (before the first decode: the kernels' LDS limit is set once)
     else if (!strcmp(key, "dec_wide_rows")) g_dec_wide_rows = (int)value;
     else if (!strcmp(key, "dec_attn_small_grid")) g_dec_attn_small_grid = (int)value;
+    else if (!strcmp(key, "dec_attn_split_max")) g_dec_attn_split_max = (int)value;
     else if (!strcmp(key, "dbg_skip")) s->dbg_skip = (int)value;          // tools/bench_decode_step.py: 1 = no attention, 2 = no GEMMs/norms (timing only; results are garbage)
     else if (!strcmp(key, "fuse_norm")) s->fuse_norm = (int)value;
     else if (!strcmp(key, "dec_norm_mfma")) g_dec_norm_mfma = (int)value;

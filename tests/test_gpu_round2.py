@@ -184,6 +184,7 @@ def test_wide_group_step_is_bitexact(cz, czo, shape, path):
         gcfg, ocfg, V, n_tok, seed = cz.smollm2_135m_config(), czo.smollm2_135m_config(), 49152, 40, 0x5EED
     g = cz.Session("smollm", gcfg, seed=seed, embed_std=0.05 if shape == "tiny" else 0.02, max_streams=6)
     o = czo.SmolLmSession(ocfg, seed=seed, embed_std=0.05 if shape == "tiny" else 0.02)
+    g.debug_set("dec_attn_split_max", 0 if path in ("tiled", "np2", "hybrid", "mid8") else 128)   # small groups: the one-kernel forms below (0) / the three-launch split form (round 3)
     g.debug_set("dec_attn_small_grid", 0 if path in ("tiled", "np2") else 128)   # decode attention with 8 waves per block (whole-device grids) / 16 (small grids)
     g.debug_set("dec_attn_split_heads", 0 if path == "hybrid" else 1)            # small grids: a block per kv head (0) / per query head (1, the default)
     if path == "tiled":
@@ -218,7 +219,7 @@ def test_wide_group_step_is_bitexact(cz, czo, shape, path):
         for s_, out, (_, z) in zip(streams, outs, coded):
             if z == 0:
                 assert np.array_equal(out, s_)
-    g.debug_set("dec_wide_rows", 256); g.debug_set("dec_attn_small_grid", 128); g.debug_set("mid_nw", 4); g.debug_set("dec_attn_split_heads", 1)
+    g.debug_set("dec_wide_rows", 256); g.debug_set("dec_attn_small_grid", 128); g.debug_set("mid_nw", 4); g.debug_set("dec_attn_split_heads", 1); g.debug_set("dec_attn_split_max", 128)
     g.close(); o.close()
 
 

@@ -253,3 +253,43 @@ def test_rwkv7_wide_group_step_is_bitexact(cz, czo, shape):
         for s_, out in zip(streams, g.decode_tokens_batch(pays, lens)):
             assert np.array_equal(out, s_), no_graph
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("shape", ["tiny", "135m"])
+def test_split_decode_attention_of_small_groups_is_bitexact(cz, czo, shape):
+    """the three-launch decode attention small groups take (scores per (head, chunk) block; softmax statistics + P.V partials; ordered sum) against
+    the oracle and against the one-kernel forms: trait steps up to a context of 130 keys (three chunks), a lock-step decode of ragged streams across a
+    re-prime (511 -> 700 keys), graph replay and eager"""
+    if shape == "tiny":
+        gcfg, ocfg, V, n_tok, seed, std = cz.tiny_llama_config(), czo.tiny_llama_config(), 512, 700, 11, 0.05
+    else:
+        gcfg, ocfg, V, n_tok, seed, std = cz.smollm2_135m_config(), czo.smollm2_135m_config(), 49152, 70, 0x5EED, 0.02
+    g = cz.Session("smollm", gcfg, seed=seed, embed_std=std, max_streams=3)
+    o = czo.SmolLmSession(ocfg, seed=seed, embed_std=std)
+    rng = np.random.default_rng(33)
+    toks = rng.integers(0, V, 140).astype(np.uint32)
+    g.debug_set("dec_attn_split_max", 128)
+    a = g.reprime_with_history_and_get_last_logits_tensor(toks[:60]); b = o.reprime_logits(toks[:60])
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for t in toks[60:132]:                                                       # 61 .. 132 keys: the chunk count goes 1 -> 3 on the way
+        a = g.step_logits_tensor(t); b = o.step_logits(t)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    lens = [n_tok, n_tok // 3, 2]
+    streams = [np.concatenate([[0], rng.integers(0, V, n)]).astype(np.uint32) for n in lens]
+    pairs = g.encode_tokens_batch(streams)
+    coded = [cz.ac_encode_pairs(lo, hi) for lo, hi in pairs]
+    ref = o.decode_tokens(coded[0][0], lens[0])
+    outs = {}
+    for split in (128, 0):
+        g.debug_set("dec_attn_split_max", split)
+        for no_graph in (0, 1):
+            g.debug_set("no_graph", no_graph)
+            outs[(split, no_graph)] = g.decode_tokens_batch([p for p, _ in coded], lens)
+            assert np.array_equal(outs[(split, no_graph)][0], ref), (split, no_graph)
+    for k in outs:
+        for x, y, (_, z), s_ in zip(outs[k], outs[(0, 1)], coded, streams):
+            assert np.array_equal(x, y)
+            if z == 0:
+                assert np.array_equal(x, s_)
+    g.debug_set("dec_attn_split_max", 128); g.debug_set("no_graph", 0)
+    g.close(); o.close()
