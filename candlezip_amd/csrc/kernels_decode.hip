@@ -845,12 +845,18 @@ __global__ __launch_bounds__(64) void da_split_pv_kernel(const cz_seq_desc* __re
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const float y = __shfl_xor(m, o); m = y > m ? y : m; }
     const float* sc = SC + hb * (DA_SPLIT_MAXC * 64);
+    float scv[DA_SPLIT_MAXC];
+#pragma unroll
+    for (int cc = 0; cc < DA_SPLIT_MAXC; ++cc) scv[cc] = sc[(cc < nch ? cc : nch - 1) * 64 + lane];     // every chunk's score of this lane in flight at once (a
+                                                                                                        // loop on the runtime chunk count is a chain of L2 round trips)
     float mine = 0.0f;
-    for (int cc = 0; cc < nch; ++cc) {
-        const float e = cz_expf(sc[cc * 64 + lane] - m);
-        E[cc][lane] = e;
-        if (cc == c) mine = e;
-    }
+#pragma unroll
+    for (int cc = 0; cc < DA_SPLIT_MAXC; ++cc)
+        if (cc < nch) {
+            const float e = cz_expf(scv[cc] - m);
+            E[cc][lane] = e;
+            if (cc == c) mine = e;
+        }
     __syncthreads();
     if (lane < nch) {                                                            // canonical chunk sum: acc = acc + e_k, k ascending from +0
         float acc = 0.0f;
@@ -885,7 +891,9 @@ __global__ __launch_bounds__(64) void da_split_sum_kernel(const cz_seq_desc* __r
     O[(size_t)sd.row0 * ldo + (out_kq ? kq_index(col) : col)] = t;
 }
 size_t cz_dec_attn_split_bytes(int nstreams, int n_heads) { return (size_t)nstreams * n_heads * ((size_t)DA_SPLIT_MAXC * 64 + DA_SPLIT_MAXC + (size_t)DA_SPLIT_MAXC * 64) * sizeof(float); }
-int g_dec_attn_split_max = 128;     // tuning knob (cz_debug_set "dec_attn_split_max"): groups with nstreams x n_heads <= this take the three-launch form (0 = never)
+int g_dec_attn_split_max = 36;      // tuning knob (cz_debug_set "dec_attn_split_max"): groups with nstreams x n_heads <= this take the three-launch form (0 = never).  Measured at
+                                    // 767 keys (profiles/r03_steps_split_attention.jsonl): B = 1: 1.379 ms per step against 1.417 for the one-kernel form, B = 4: 1.474,
+                                    // B = 8: 1.566 against 1.543 — the three launches pay for a handful of streams only
 #define DA_LONG_W 16
 #define DA_LONG_C 8                                   // 16 waves x 8 chunks x 64 keys = 8192 positions
 static int da_s_stride(int max_nk) { return ((max_nk + 63) / 64) * 64 + 4; }
