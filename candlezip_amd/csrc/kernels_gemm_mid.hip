@@ -21,6 +21,24 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// tuning build (make mid_dbg, tools/mid_phases.py): wave 0 of the FIRST and of the LAST block of a launch accumulate s_memrealtime ticks (10 ns) per
+// phase; every stamp first waits for the wave's outstanding memory operations
+#ifdef CZ_MID_STAMPS
+__device__ unsigned long long g_mid_stamp[8][16];
+#define MST_BEGIN const int mst_k = (EPI & 3) + ((int)blockIdx.x == (int)gridDim.x - 1 ? 4 : ((int)blockIdx.x == 0 ? 0 : -100)); unsigned long long mst_t = 0; \
+                  if (mst_k >= 0 && threadIdx.x == 0) mst_t = wall_clock64()
+#define MST(ph) do { if (mst_k >= 0 && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = wall_clock64(); atomicAdd(&g_mid_stamp[mst_k][ph], t_ - mst_t); \
+                     if ((ph) == 15) atomicAdd(&g_mid_stamp[mst_k][0], 1ull); mst_t = t_; } } while (0)
+extern "C" void cz_debug_mid_stamps(unsigned long long* out128, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_mid_stamp), sizeof(unsigned long long) * 128);
+    if (reset) { unsigned long long z[128] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_mid_stamp), z, sizeof z); }
+}
+#else
+#define MST_BEGIN do { } while (0)
+#define MST(ph) do { } while (0)
+#endif
+
 #define MID_LDK 68   // LDS row stride of the activation tile in floats (64 + 4: ds_read_b128 by 16 consecutive rows is conflict-free)
 
 // Wk[n'][c*64 + h*32 + t] = W[n][c*64 + 2t + h].  The first `rot_heads` 64-row heads are stored with their rows reordered so that a
@@ -58,7 +76,12 @@ __device__ __forceinline__ int mid_xcd_remap(int bid, int nblocks) {    // block
 // straight to the stream's KV cache at *pos_dev — what rope_kernel did in a launch of its own.
 // EPI = 3: C = relu(A.W^T)^2 (the RWKV7 channel-mix key projection, rwkv7.rs:426).
 // The tile (bm, bn) of one problem; the kernels below pick the tile.
-template <int TN, int EPI, int NW, bool PF>
+// QE ("quad epilogue"): the ordered sum of the chunk partials AND the epilogue are shared by waves 0..3 — wave w owns registers 4w..4w+3 of the
+// 32 x 32 C/D tile (rows 8w + {0..3} + 4 (lane >> 5)): every wave parks its partial tile, one barrier, wave w adds ITS quad of every parked tile in
+// K order (the same left-to-right order: an element's sum does not care which wave forms it), a second barrier frees the tiles.  With !QE wave 0
+// alone adds all sixteen registers of every partial and runs the whole epilogue (RoPE + cache scatter, SwiGLU's exp and division: 3-4 us of a
+// 14-22 us block, profiles/r03_mid_phases_b512_before_quad_epilogue.json) while waves 1..3 have nothing to do.
+template <int TN, int EPI, int NW, bool PF, bool QE>
 __device__ __forceinline__ void gemm_mid_body(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Wk,
                                               float* __restrict__ C, int ldc, const float* __restrict__ R, int ldr,
                                               int M, int N, int K, const int bm, const int bn, const mid_rope_args& ra_) {
@@ -116,16 +139,18 @@ __device__ __forceinline__ void gemm_mid_body(const float* __restrict__ A, int l
     };
 
     f32x16 tot[TN];
-    if (PF) {
+    if (PF || QE) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) tot[j][r] = 0.0f;
     }
+    MST_BEGIN;
     if (wave < nk) load_tile(wave);
+    MST(1);                                                              // first operand tile arrived
     for (int rd = 0; rd < rounds; ++rd) {
         const int kt = rd * NW + wave;
-        if (PF) {
+        if (PF && !QE) {
             if (wave == 0) {
                 if (rd > 0) add_partials(tot, (rd - 1) * NW);             // (complete since the barrier that ended the previous round)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -135,6 +160,7 @@ __device__ __forceinline__ void gemm_mid_body(const float* __restrict__ A, int l
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
         }
+        MST(2);                                                          // (wave 0) partials of the previous round added, flag raised
         if (kt < nk) {
             store_tile();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -166,7 +192,7 @@ __device__ __forceinline__ void gemm_mid_body(const float* __restrict__ A, int l
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_s_waitcnt(0xc07f);                        // (the reads of As are done before the partial goes on top of it)
-            if (wave == 0) {
+            if (!QE && wave == 0) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -179,10 +205,36 @@ __device__ __forceinline__ void gemm_mid_body(const float* __restrict__ A, int l
                         *reinterpret_cast<f32x4*>(As + ((j * 4 + q) * 64 + lane) * 4) = f32x4{acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
             }
         }
+        MST(3);                                                          // staging + MFMA chain of the round (the next tile's loads waited for too)
         __syncthreads();                                                // one barrier per round: the partials of round rd are complete
+        MST(4);                                                          // barrier
+        if (QE) {
+            if (wave < 4) {                                               // quad `wave` of every tile parked this round, chunks rd * NW + v in order
+#pragma unroll
+                for (int v = 0; v < NW; ++v)
+                    if (rd * NW + v < nk) {
+                        const float* sp = smem + v * (32 * MID_LDK);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const f32x4 q = *reinterpret_cast<const f32x4*>(sp + ((j * 4 + wave) * 64 + lane) * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) tot[j][e] = (rd == 0 && v == 0) ? q[e] : tot[j][e] + q[e];      // (tot[j][0..3] = this wave's quad)
+                        }
+                    }
+            }
+            MST(5);
+            if (rd + 1 < rounds) __syncthreads();                        // the parked tiles are free for the next round's activations
+        }
     }
-    if (wave != 0) return;
-    add_partials(tot, (rounds - 1) * NW);
+    if (QE) { if (wave >= 4) return; }
+    else {
+        if (wave != 0) return;
+        add_partials(tot, (rounds - 1) * NW);
+        MST(5);                                                              // last round's partials added
+    }
+    // QE: this wave holds registers 4 wave .. 4 wave + 3 of the tile in tot[j][0..3]; !QE: wave 0 holds all sixteen
+    constexpr int NR = QE ? 4 : 16;
+    const int r0 = QE ? 4 * wave : 0;
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     if (EPI == 2) {
         const int pos = ra_.pos_dev ? *ra_.pos_dev : ra_.descs[0].pos0;
@@ -193,9 +245,10 @@ __device__ __forceinline__ void gemm_mid_body(const float* __restrict__ A, int l
             const float c = ra_.cs[(size_t)pos * 32 + t], sn = ra_.sn[(size_t)pos * 32 + t];
             const int dim = t + (lo ? 0 : 32);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int e = 0; e < NR; ++e) {
+                const int r = r0 + e;
                 const int row = bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float mine = tot[0][r], other = __shfl_xor(mine, 16);
+                const float mine = tot[0][e], other = __shfl_xor(mine, 16);
                 const float x1 = lo ? mine : other, x2 = lo ? other : mine;
                 const float pa = x1 * (lo ? c : sn), pb = x2 * (lo ? sn : c);      // lo: x1 c, x2 s; hi: x1 s, x2 c
                 const float o = lo ? pa - pb : pa + pb;
@@ -212,41 +265,47 @@ __device__ __forceinline__ void gemm_mid_body(const float* __restrict__ A, int l
         } else {
             const int vc = col0 - nrot + lr;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int e = 0; e < NR; ++e) {
+                const int r = r0 + e;
                 const int row = bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < M) { const cz_rope_desc d = ra_.descs[row]; d.v_dst[ra_.kv_off + (size_t)pos * d.dst_stride + vc] = tot[0][r]; }
+                if (row < M) { const cz_rope_desc d = ra_.descs[row]; d.v_dst[ra_.kv_off + (size_t)pos * d.dst_stride + vc] = tot[0][e]; }
             }
         }
+        MST(15);
         return;
     }
     if (EPI == 1) {
         const int hcol = (bn * (32 * TN)) / 2 + lr;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int e = 0; e < NR; ++e) {
+            const int r = r0 + e;
             const int row = bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row < M) C[(size_t)row * ldc + hcol] = cz_siluf(tot[0][r]) * tot[TN - 1][r];      // silu(gate) * up (llama.rs MLP)
+            if (row < M) C[(size_t)row * ldc + hcol] = cz_siluf(tot[0][e]) * tot[TN - 1][e];      // silu(gate) * up (llama.rs MLP)
         }
+        MST(15);
         return;
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = bn * (32 * TN) + j * 32 + lr;
-        float rv[16];                                                     // (all residual loads in flight together: see gemm_bf16w_kernel)
+        float rv[NR];                                                     // (all residual loads in flight together: see gemm_bf16w_kernel)
         if (R) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rv[r] = R[(size_t)min(bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1) * ldr + col];
+            for (int e = 0; e < NR; ++e) { const int r = r0 + e; rv[e] = R[(size_t)min(bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1) * ldr + col]; }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int e = 0; e < NR; ++e) {
+            const int r = r0 + e;
             const int row = bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            float v = R ? tot[j][r] + rv[r] : tot[j][r];
-            if (EPI == 3) { const float z = tot[j][r] > 0.0f ? tot[j][r] : 0.0f; v = z * z; }
+            float v = R ? tot[j][e] + rv[e] : tot[j][e];
+            if (EPI == 3) { const float z = tot[j][e] > 0.0f ? tot[j][e] : 0.0f; v = z * z; }
             if (row < M) C[(size_t)row * ldc + col] = v;
         }
     }
+    MST(15);
 }
 
-template <int TN, int EPI, int NW, bool PF>
+template <int TN, int EPI, int NW, bool PF, bool QE>
 __global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : 1) void gemm_mid_kernel(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Wk,
                                                            float* __restrict__ C, int ldc, const float* __restrict__ R, int ldr,
                                                            int M, int N, int K, int nbx, int nblocks, int colmaj, mid_rope_args ra_) {
@@ -257,7 +316,7 @@ __global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : 1) void gemm_mi
     const int sid = mid_xcd_remap(blockIdx.x, nblocks);
     const int nby = nblocks / nbx;
     const int bm = colmaj ? sid % nby : sid / nbx, bn = colmaj ? sid / nby : sid % nbx;
-    gemm_mid_body<TN, EPI, NW, PF>(A, lda, Wk, C, ldc, R, ldr, M, N, K, bm, bn, ra_);
+    gemm_mid_body<TN, EPI, NW, PF, QE>(A, lda, Wk, C, ldc, R, ldr, M, N, K, bm, bn, ra_);
 }
 
 // Several independent plain GEMMs that share M in ONE launch (the RWKV7 time-mix: seven projections of differently mixed inputs, then four
@@ -274,15 +333,16 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_mid_group_kernel(mid_group g,
     for (int q = 1; q < MID_GROUP_MAX; ++q) if (q < g.n && sid >= g.tile0[q]) z = q;
     const mid_prob pr = g.p[z];
     const int local = sid - g.tile0[z], nby = (M + 31) / 32;
-    gemm_mid_body<1, 0, NW, PF>(pr.A, pr.lda, pr.Wk, pr.C, pr.ldc, nullptr, 0, M, pr.N, pr.K, local % nby, local / nby, mid_rope_args{});
+    gemm_mid_body<1, 0, NW, PF, true>(pr.A, pr.lda, pr.Wk, pr.C, pr.ldc, nullptr, 0, M, pr.N, pr.K, local % nby, local / nby, mid_rope_args{});
 }
 
+int g_mid_quad = 1;           // tuning knob (cz_debug_set "mid_quad"): 1 = the four-wave blocks share the ordered sum and the epilogue (QE), 0 = wave 0 does both
 int g_mid_colmaj = -1;        // tuning knob (cz_debug_set "mid_colmaj"): -1 = by operand sizes, 0 = row-major tile order, 1 = column-major
 template <int TN, int EPI, int NW, bool PF>
 static hipError_t launch_mid_nw(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* C, int ldc, const float* R, int ldr, int M, int N, int K,
                                 mid_rope_args ra) {
     const size_t smem = (size_t)(NW * 32 * MID_LDK + 4) * sizeof(float);
-    auto kern = gemm_mid_kernel<TN, EPI, NW, PF>;            // (LDS limit: cz_gemm_mid_prepare, once per device at session open)
+    auto kern = g_mid_quad ? gemm_mid_kernel<TN, EPI, NW, PF, true> : gemm_mid_kernel<TN, EPI, NW, PF, false>;   // (LDS limit: cz_gemm_mid_prepare, once per device at session open)
     const int nbx = N / (32 * TN), nby = (M + 31) / 32, nblocks = nbx * nby;
     // bytes fetched over the eight XCD L2s: row-major = 8 x weights + activations, column-major = weights + 8 x activations
     const double wb = (double)N * K * 2, ab = (double)M * K * 4;
@@ -292,8 +352,11 @@ static hipError_t launch_mid_nw(hipStream_t st, const float* A, int lda, const u
 }
 template <int TN, int EPI, int NW, bool PF>
 static hipError_t mid_prepare_one() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_mid_kernel<TN, EPI, NW, PF>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)((size_t)(NW * 32 * MID_LDK + 4) * sizeof(float)));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_mid_kernel<TN, EPI, NW, PF, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)((size_t)(NW * 32 * MID_LDK + 4) * sizeof(float)));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_mid_kernel<TN, EPI, NW, PF, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)((size_t)(NW * 32 * MID_LDK + 4) * sizeof(float)));
+    return e;
 }
 template <int TN, int EPI>
 static hipError_t mid_prepare_epi() {
@@ -312,7 +375,9 @@ hipError_t cz_gemm_mid_prepare() {
                                                  (int)((size_t)(4 * 32 * MID_LDK + 4) * sizeof(float)));
     return e;
 }
-// K groups per block.  Measured on 512-row groups (profiles/r02_microbench/call24_*): four groups with operand prefetch beat a wave per
+// K groups per block.  Round 3, with the ordered sum and the epilogue shared by four waves (QE), 512 rows, ms per decode step
+// (profiles/r03_steps_mid_k_groups.jsonl): four groups 6.29-6.36, five (K = 576 in two rounds instead of 4 + 4 + 1) 6.39, six 6.47, eight 6.60, one
+// wave per chunk (nine / twelve) 6.45; wave 0 doing sum and epilogue alone (!QE) 6.62.  Round 2, measured on 512-row groups (profiles/r02_microbench/call24_*): four groups with operand prefetch beat a wave per
 // 64-chunk (nine waves, one round for K = 576: +8 % step time) and summing on the round's last wave instead of its first (the wave with
 // the fewest K tiles: +2 %, call26) — a block's latency is dominated by its first, cold operand load and by
 // the 0.85 us dependent MFMA chain per chunk, and four-wave blocks pack four to a CU where nine-wave blocks pack one or two.

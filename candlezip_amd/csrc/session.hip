@@ -31,6 +31,7 @@ extern int g_dec_norm_mfma;
 extern int g_gemm_mid_rows;
 extern int g_mid_nw;
 extern int g_mid_colmaj;
+extern int g_mid_quad;
 extern int g_dec_attn_split_heads;
 extern int g_dec_attn_lds_pad;
 extern int g_dec_wide_rows;
@@ -1511,6 +1512,7 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "rwkv_seq_rows")) g_rw_seq_rows = (int)value < 1 ? 1 : (int)value;
     else if (!strcmp(key, "mid_nw")) g_mid_nw = (int)value;
     else if (!strcmp(key, "mid_colmaj")) g_mid_colmaj = (int)value;
+    else if (!strcmp(key, "mid_quad")) g_mid_quad = (int)value;
     else if (!strcmp(key, "dec_attn_split_heads")) g_dec_attn_split_heads = (int)value;
     else if (!strcmp(key, "dec_attn_lds_pad")) g_dec_attn_lds_pad = (int)value;              // (before the first decode: the kernels' LDS limit is set once)
     else if (!strcmp(key, "dec_wide_rows")) g_dec_wide_rows = (int)value;

@@ -169,14 +169,15 @@ def _eq(a, b, what):
     assert n == 0, f"{what}: {n}/{a.size} logits differ"
 
 
-@pytest.mark.parametrize("path", ["tiled", "np2", "hybrid", "mid", "mid8", "mid9"])
+@pytest.mark.parametrize("path", ["tiled", "np2", "hybrid", "mid", "mid_q0", "mid8", "mid9"])
 @pytest.mark.parametrize("shape", ["tiny", "135m"])
 def test_wide_group_step_is_bitexact(cz, czo, shape, path):
     """the decode step of ONE WIDE lock-step group against the oracle: every logit of the trait steps, the coder intervals, and a lock-step
     decode across a re-prime, graph replay and eager.  Two forms: "tiled" = tiled MFMA GEMMs with 64-row tiles + rope kernel + dec_attn with
     natural-layout output; "np2" = dec_gemm_kernel with 32-row x 64-column blocks (MT = 2, NP = 2), the shape groups of >= 256 streams take;
     "hybrid" = tiled QKV / lm_head projections, the rest on the 32 x 64 blocks; "mid" = gemm_mid_kernel (32 x 32 tiles, four K groups per
-    block, ordered hand-off of the chunk partials, RoPE + cache write in the QKV epilogue) for the layer projections; "mid8" / "mid9" = the
+    block, ordered hand-off of the chunk partials, RoPE + cache write in the QKV epilogue) for the layer projections — the four waves sharing
+    the ordered sum and the epilogue by register quads ("mid", round 3) or wave 0 doing both ("mid_q0"); "mid8" / "mid9" = the
     same with eight K groups / one wave per 64-chunk (nine for K = 576, twelve in two rounds for K = 1536): the `mid_nw` tuning knob"""
     if shape == "tiny":
         gcfg, ocfg, V, n_tok, seed = cz.tiny_llama_config(), czo.tiny_llama_config(), 512, 700, 11
@@ -192,7 +193,8 @@ def test_wide_group_step_is_bitexact(cz, czo, shape, path):
         g.debug_set("no_last_prune", 1)                                   # ... and the last layer runs its tail on every row (the other paths: wanted rows only)
     elif path.startswith("mid"):                                          # the K-group GEMM (kernels_gemm_mid.hip) for the four layer projections
         g.debug_set("wide_min_streams", 1); g.debug_set("wide_mode", 3)
-        g.debug_set("mid_nw", {"mid": 4, "mid8": 8, "mid9": 0}[path])     # (process-wide knob: reset below)
+        g.debug_set("mid_nw", {"mid": 4, "mid_q0": 4, "mid8": 8, "mid9": 0}[path])     # (process-wide knob: reset below)
+        g.debug_set("mid_quad", 0 if path == "mid_q0" else 1)             # four-wave blocks: wave 0 alone sums and runs the epilogue (0) / all four waves share both (1, the default)
     elif path == "hybrid":                                                # tiled QKV / lm_head, dec_gemm 32 x 64 blocks for the other projections
         g.debug_set("wide_min_streams", 1); g.debug_set("wide_mode", 2); g.debug_set("dec_wide_rows", 1)
     else:
@@ -219,7 +221,7 @@ def test_wide_group_step_is_bitexact(cz, czo, shape, path):
         for s_, out, (_, z) in zip(streams, outs, coded):
             if z == 0:
                 assert np.array_equal(out, s_)
-    g.debug_set("dec_wide_rows", 256); g.debug_set("dec_attn_small_grid", 128); g.debug_set("mid_nw", 4); g.debug_set("dec_attn_split_heads", 1); g.debug_set("dec_attn_split_max", 128)
+    g.debug_set("dec_wide_rows", 256); g.debug_set("dec_attn_small_grid", 128); g.debug_set("mid_nw", 4); g.debug_set("dec_attn_split_heads", 1); g.debug_set("dec_attn_split_max", 128); g.debug_set("mid_quad", 1)
     g.close(); o.close()
 
 
