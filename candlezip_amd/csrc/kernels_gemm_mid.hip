@@ -306,7 +306,7 @@ __device__ __forceinline__ void gemm_mid_body(const float* __restrict__ A, int l
 }
 
 template <int TN, int EPI, int NW, bool PF, bool QE>
-__global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : 1) void gemm_mid_kernel(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Wk,
+__global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : ((TN == 2 && NW == 4 && QE) ? 3 : 1)) void gemm_mid_kernel(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Wk,
                                                            float* __restrict__ C, int ldc, const float* __restrict__ R, int ldr,
                                                            int M, int N, int K, int nbx, int nblocks, int colmaj, mid_rope_args ra_) {
     // An XCD (blocks b, b + 8, ...: speed only) takes a contiguous range of tiles.  Row-major numbering gives it a few row tiles x ALL column
