@@ -64,8 +64,10 @@ def pmc_traffic(prefix, tokens=2048):
     tot = 0.0; notes = []
     for counter, scale in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
         # the pass of the same length as the eager profiling pass first (r<round>_pmc<tokens>_...), newest round first; then any other
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc{tokens}_{counter}_pmc.json")), reverse=True) + \
-            sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc*_{counter}_pmc.json")), reverse=True)
+        # (a pass of the OTHER backend never: both hold gemm_mid_kernel / gemm_bf16w_kernel, on different shapes)
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc{tokens}_{counter}_pmc.json")), reverse=True)
+        if str(tokens).isdigit():
+            files += sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc[0-9]*_{counter}_pmc.json")), reverse=True)
         hit = None
         for f in files:
             d = json.load(open(f))

@@ -1,0 +1,11 @@
+#!/bin/bash
+# round-3 GPU call 19: rocprofv3 --kernel-trace of both profile passes at the final kernels (gemm_mid with the quad epilogue)
+set -o pipefail
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3c19; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+run() { local name=$1; shift; timeout -k 10 900 rocprofv3 "$@" > $O/$name.out 2> $O/$name.err; local rc=$?; echo "$name rc=$rc"; grep "profile_pass\]" $O/$name.err | tail -1; return $rc; }
+run kt_smollm --kernel-trace --output-format csv -d $O/kt_smollm -- python3 $R/tools/profile_pass.py smollm || exit 1
+python3 $R/tools/prof_summary.py $O/kt_smollm $O/r03_pass2048_s512 --skip-frac 0.25; rm -rf $O/kt_smollm; head -14 $O/r03_pass2048_s512_kernel_stats.csv
+run kt_rwkv7 --kernel-trace --output-format csv -d $O/kt_rwkv7 -- python3 $R/tools/profile_pass.py rwkv7 || exit 1
+python3 $R/tools/prof_summary.py $O/kt_rwkv7 $O/r03_passrwkv7_s256_t512 --skip-frac 0.0001; rm -rf $O/kt_rwkv7; head -12 $O/r03_passrwkv7_s256_t512_kernel_stats.csv
+exit 0

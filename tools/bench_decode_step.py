@@ -17,7 +17,7 @@ import candlezip_amd as cz
 WM = [256, 1]
 
 
-def run_config(parent, cfgs, name, B, L, pos, x, av, fn, g, prof, iters, sym):
+def run_config(parent, cfgs, name, B, L, pos, x, av, fn, g, prof, iters, sym, av1=-1, pr0=0, pr1=0):
     lib = cz.lib()
     lib.cz_debug_decode_steps.restype = C.c_int
     lib.cz_debug_decode_steps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
@@ -27,7 +27,9 @@ def run_config(parent, cfgs, name, B, L, pos, x, av, fn, g, prof, iters, sym):
         if x:
             nx = max(1, 8 // L)
             s.debug_set("cu_mask_xcd", (k * nx) % 8 + 16 * (nx - 1))
-        s.debug_set("dbg_skip", av)
+        s.debug_set("dbg_skip", av1 if (k & 1) and av1 >= 0 else av)       # av1: the odd lanes' dbg_skip (attention-only lanes beside chain-only lanes)
+        if (pr1 if k & 1 else pr0):
+            s.debug_set("stream_priority", pr1 if k & 1 else pr0)           # -1 = high, 1 = low
         s.debug_set("fuse_norm", fn)
         s.debug_set("wide_min_streams", WM[0]); s.debug_set("wide_mode", WM[1])
     ms = [0.0] * L; err = []
@@ -75,7 +77,7 @@ def main():
     parent = cz.Session("smollm", cz.smollm2_135m_config(), seed=0x5EED, embed_std=0.02, max_streams=args.max_streams)
     for c in args.configs:
         name, _, kv = c.partition(":")
-        d = dict(B=128, L=1, pos=767, x=0, av=0, fn=0, g=1, prof=0, gt=384, mt=8, wm=256, dw=256, wmode=1, nw=4, pad=0, mq=1, sp=36)
+        d = dict(B=128, L=1, pos=767, x=0, av=0, fn=0, g=1, prof=0, gt=384, mt=8, wm=256, dw=256, wmode=1, nw=4, pad=0, mq=1, sp=36, av1=-1, pr0=0, pr1=0)
         for item in kv.split(","):
             if item:
                 k, v = item.split("=")
@@ -83,7 +85,7 @@ def main():
         parent.debug_set("dec_grid_target", d["gt"]); parent.debug_set("dec_mt_max", d["mt"])     # (process-wide knobs)
         WM[0] = d["wm"]; WM[1] = d["wmode"]; parent.debug_set("dec_wide_rows", d["dw"]); parent.debug_set("mid_nw", d["nw"]); parent.debug_set("dec_attn_lds_pad", d["pad"])
         parent.debug_set("mid_quad", d["mq"]); parent.debug_set("dec_attn_split_max", d["sp"])     # mq: gemm_mid blocks share sum + epilogue over their waves; sp: split attention up to this many (stream, head) pairs
-        run_config(parent, None, name + f"[gt={d['gt']}]", d["B"], d["L"], d["pos"], d["x"], d["av"], d["fn"], d["g"], d["prof"], args.iters, args.sym)
+        run_config(parent, None, name + f"[gt={d['gt']}]", d["B"], d["L"], d["pos"], d["x"], d["av"], d["fn"], d["g"], d["prof"], args.iters, args.sym, d["av1"], d["pr0"], d["pr1"])
     parent.close()
 
 
