@@ -19,6 +19,23 @@ __device__ __forceinline__ uint32_t quantize(double acc, uint32_t prev) {   // s
     return (uint32_t)v;
 }
 
+// a / b correctly rounded (== the IEEE division the reference does, bit for bit) for a divisor b that a whole row shares: y = 1.0 / b is
+// taken ONCE (a true division), every quotient is then one multiply and four fused multiply-adds instead of the ~11-instruction division
+// sequence with its quarter-rate v_rcp_f64.  Why it is exact (round to nearest, no under-/overflow: here 0 <= a <= 1 or a few units, 1 <= b
+// < 2^17, quotients above 2^-170):  y = RN(1/b), so q0 = RN(a y) is within 1.5 ulp of a/b;  r0 = RN(a - b q0) and q1 = RN(q0 + r0 y)
+// leave q1 within 1/2 ulp + 2^-51 ulp of a/b, i.e. FAITHFUL;  for a faithful q1 the remainder r1 = a - b q1 is a floating-point
+// number (the fma computes it exactly) and Markstein's theorem (Markstein 1990; Muller et al., Handbook of Floating-Point Arithmetic,
+// "division with an FMA") gives RN(q1 + r1 y) = RN(a / b) whenever y is the correctly rounded reciprocal.  a = 0 gives +0 like 0 / b.
+// Checked against the division itself: tests/test_div_by_reciprocal.py (exact rational model, quotients next to rounding midpoints,
+// divisors with all-ones significands) and test_gpu_kernels.py::test_division_by_shared_reciprocal_is_exact (the device function).
+__device__ __forceinline__ double div_by(double a, double b, double y) {
+    double q = a * y;
+    double r = __builtin_fma(-b, q, a);
+    q = __builtin_fma(r, y, q);
+    r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+
 // per-row constants of the pdf; pdf_at() then yields pdf[i] exactly as the reference computes it
 struct pdf_ctx {
     const float* l; int V, n, mode; float mx; double sum, norm, sum2, scale, lit; bool uniform;

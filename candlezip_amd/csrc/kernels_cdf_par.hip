@@ -336,16 +336,18 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
         const double p_escape_total = 256.0 * P_MIN;             // :771
         const double scale = (1.0 - p_escape_total) > 0.0 ? (1.0 - p_escape_total) : 0.0;
         const double lit = p_escape_total > 0.0 ? p_escape_total / 256.0 : 0.0;
-        auto fl = [&](int k) { const double p = (double)ef[k] / sum; return p > P_MIN ? p : P_MIN; };            // (exps/sum).max(p_floor)
-        auto mix = [&](int k) { return k < cntA ? (fl(k) / norm) * scale : lit; };                                 // base[i] /= norm; *= scale | literal
+        // every division of a row is by one of three row-wide divisors: div_by() with their correctly rounded reciprocals (cz_cdf_common.h: same bits)
+        const double inv_sum = 1.0 / sum;
+        double inv_norm = 1.0, inv_sum2 = 1.0;
+        auto fl = [&](int k) { const double p = div_by((double)ef[k], sum, inv_sum); return p > P_MIN ? p : P_MIN; };   // (exps/sum).max(p_floor)
+        auto mix = [&](int k) { return k < cntA ? div_by(fl(k), norm, inv_norm) * scale : lit; };                       // base[i] /= norm; *= scale | literal
         auto pd = [&](int k) {
-            if (MODE == 0) return (double)ef[k] / sum;
+            if (MODE == 0) return div_by((double)ef[k], sum, inv_sum);
             const double x = mix(k);
-            return sum2 > 0.0 ? x / sum2 : x;                                                                    // :779
+            return sum2 > 0.0 ? div_by(x, sum2, inv_sum2) : x;                                                       // :779
         };
         if (MODE == 1 && !fallback) {
-            // approximate chunk sums (they only steer the binade guesses): reciprocal multiply instead of a division per term
-            const double inv_sum = 1.0 / sum;
+            // approximate chunk sums (they only steer the binade guesses): reciprocal multiply, no correction steps
             double cs = 0.0;
 #pragma unroll
             for (int k = 0; k < LMAX; ++k) if (k < cntA) { const double p = (double)ef[k] * inv_sum; cs += p > P_MIN ? p : P_MIN; }
@@ -354,11 +356,13 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
             fallback = sm.flag != 0 || !(norm > 0.0);
             if (!fallback) {
                 if (tid == 0) sm.n = n;                          // the last two chains run over vocabulary + literals
+                inv_norm = 1.0 / norm;
                 const double cs2 = cs * (scale / norm) + (double)(cnt - cntA) * lit;
                 sum2 = exact_seq_sum<LMAX>(mix, cs2, cnt, first, sm, scratch, false, nullptr, ph_t, tid);
                 PH(3);
                 fallback = sm.flag != 0 || !(sum2 > 0.0);
                 if (!fallback) {
+                    inv_sum2 = 1.0 / sum2;
                     exact_seq_sum<LMAX>(pd, cs2 / sum2, cnt, first, sm, scratch, true, &acc, ph_t, tid);
                     fallback = sm.flag != 0;
                 }
@@ -491,10 +495,10 @@ __global__ __launch_bounds__(T_PAR) void xe_prob_kernel(const float* __restrict_
         for (int k = 0; k < LMAX; ++k) if (k < cnt) { ef[k] = cz_expf(ef[k] - m); csum_e += (double)ef[k]; }
         const double sum = exact_seq_sum<LMAX>([&](int k) { return (double)ef[k]; }, csum_e, cnt, first, sm, scratch, false, nullptr, ph_t, tid);
         bool fallback = sm.flag != 0 || !(sum > 0.0);
-        auto fl = [&](int k) { const double p = (double)ef[k] / sum; return p > P_MIN ? p : P_MIN; };
+        const double inv_sum = 1.0 / sum;
+        auto fl = [&](int k) { const double p = div_by((double)ef[k], sum, inv_sum); return p > P_MIN ? p : P_MIN; };
         double norm = 1.0;
         if (!fallback) {
-            const double inv_sum = 1.0 / sum;
             double cs = 0.0;
 #pragma unroll
             for (int k = 0; k < LMAX; ++k) if (k < cnt) { const double p = (double)ef[k] * inv_sum; cs += p > P_MIN ? p : P_MIN; }

@@ -5,6 +5,7 @@
 #include <vector>
 #include "cz_host.h"
 #include "cz_kernels.h"
+#include "cz_cdf_common.h"
 
 #define PCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cz_set_error("HIP error %s at %s:%d", hipGetErrorString(_e), __FILE__, __LINE__); goto fail; } } while (0)
 
@@ -41,6 +42,7 @@ __global__ void f64_fn_kernel(int fn, const double* x, const double* y, double* 
         case 1: r = a + b; break;
         case 2: r = floor(a * 1073741824.0); break;
         case 3: r = a * b; break;
+        case 4: r = div_by(a, b, 1.0 / b); break;          // the CDF kernels' division by a row-wide divisor (cz_cdf_common.h)
         default: r = 0.0;
     }
     out[i] = r;
@@ -229,6 +231,88 @@ extern "C" cz_status cz_debug_probe_chain(int nodes, int blocks, int kb, int ite
     if (ge) hipGraphExecDestroy(ge);
     if (g) hipGraphDestroy(g);
     hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(st);
+    return CZ_OK;
+fail:
+    return CZ_ERR_HIP;
+}
+
+// ---- measurement aid (tools/probe_persist.py): what ONE all-to-all hand-off costs INSIDE a launch.  G resident blocks pass through `stages` stages;
+// in each a block (1) requests `kb` KB of "weights" (independent of the hand-off, so before it), (2) waits until every block has finished the previous
+// stage (one monotonic counter, agent scope), (3) reads the whole `xn`-float activation vector the others wrote, (4) writes its own slice of the next
+// one, (5) fences and counts itself in.  `stride` = 8 keeps only every eighth block (the others return at once): workgroups are dealt round-robin to
+// the eight XCDs, so the survivors share one L2.  Every wait is bounded (err = 1 and the block leaves), so the grid always drains.
+__global__ __launch_bounds__(256) void probe_persist_kernel(float* x, unsigned* ctr, const float4* __restrict__ w, int stages, int stride, int kb, int xn, int wslabs, int* err) {
+    if (blockIdx.x % stride) return;
+    const int g = blockIdx.x / stride, G = gridDim.x / stride, tid = threadIdx.x;
+    const int per = (xn + G - 1) / G, n4 = kb * 64 / 256;           // outputs per block; float4 of weights per thread
+    __shared__ float red[256];
+    __shared__ int bail;
+    if (tid == 0) bail = 0;
+    __syncthreads();
+    for (int s = 0; s < stages; ++s) {
+        float4 wv[16];
+        const float4* wp = w + ((size_t)(s % wslabs) * G + g) * (size_t)(kb * 64) + tid;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) if (i < n4) wv[i] = wp[i * 256];
+        if (tid == 0 && s > 0) {
+            const unsigned target = (unsigned)s * (unsigned)G;
+            int spins = 0;
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > 4000000) { bail = 1; *err = 1; break; }
+            }
+        }
+        __syncthreads();
+        if (bail) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const float* xin = x + (size_t)(s & 1) * xn;
+        float* xout = x + (size_t)((s + 1) & 1) * xn;
+        float a = 0.0f;
+        for (int i = tid; i < xn; i += 256) a += xin[i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) if (i < n4) a += (wv[i].x + wv[i].y + wv[i].z + wv[i].w) * 1e-9f;
+        red[tid] = a;
+        __syncthreads();
+        if (tid < 64) { float t = red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192]; for (int o = 32; o; o >>= 1) t += __shfl_xor(t, o); if (tid == 0) red[0] = t; }
+        __syncthreads();
+        const float tot = red[0];
+        if (tid < per && g * per + tid < xn) xout[g * per + tid] = 0.25f * xin[g * per + tid] + tot * 1e-6f;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+extern "C" cz_status cz_debug_probe_persist(int G, int stride, int stages, int kb, int xn, int iters, double* us_per_stage) {
+    DevMem m;
+    const int wslabs = 150;
+    if (G <= 0 || G > 512 || (stride != 1 && stride != 8) || stages <= 0 || kb < 0 || kb > 64 || (kb % 4) || xn <= 0 || xn > 8192 || iters <= 0) { cz_set_error("cz_debug_probe_persist: bad argument"); return CZ_ERR_ARG; }
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { cz_set_error("no device"); return CZ_ERR_HIP; }
+    if (G * stride > 2 * cus) { cz_set_error("cz_debug_probe_persist: %d blocks (stride %d) cannot all be resident on %d CUs", G, stride, cus); return CZ_ERR_ARG; }   // (two 256-thread blocks per CU fit easily)
+    const size_t wbytes = (size_t)wslabs * G * (kb ? kb : 1) * 1024;
+    float* x = (float*)m.alloc((size_t)2 * xn * 4);
+    unsigned* ctr = (unsigned*)m.alloc(64);
+    int* err = (int*)m.alloc(64);
+    float4* w = (float4*)m.alloc(wbytes);
+    if (!x || !ctr || !err || !w) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
+    hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0.0f, total = 0.0f; int herr = 0;
+    PCHK(hipMemset(x, 0, (size_t)2 * xn * 4)); PCHK(hipMemset(w, 0, wbytes)); PCHK(hipMemset(err, 0, 64));
+    PCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    PCHK(hipEventCreate(&e0)); PCHK(hipEventCreate(&e1));
+    for (int it = 0; it <= iters; ++it) {                                  // (iteration 0 is the warm-up)
+        PCHK(hipMemsetAsync(ctr, 0, 64, st));
+        PCHK(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(probe_persist_kernel, dim3(G * stride), dim3(256), 0, st, x, ctr, w, stages, stride, kb, xn, wslabs, err);
+        PCHK(hipEventRecord(e1, st));
+        PCHK(hipStreamSynchronize(st));
+        PCHK(hipEventElapsedTime(&ms, e0, e1));
+        if (it) total += ms;
+    }
+    PCHK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
+    hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(st);
+    if (herr) { cz_set_error("cz_debug_probe_persist: a hand-off timed out (blocks not co-resident?)"); return CZ_ERR_STATE; }
+    *us_per_stage = 1e3 * total / ((double)iters * stages);
     return CZ_OK;
 fail:
     return CZ_ERR_HIP;

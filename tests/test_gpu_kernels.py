@@ -67,6 +67,31 @@ def test_f32_division_and_f64_ops_are_ieee(cz):
         assert np.array_equal(o.view(np.uint64), ref.view(np.uint64)), fn
 
 
+def test_division_by_shared_reciprocal_is_exact(cz):
+    """div_by() (csrc/cz_cdf_common.h): the CDF kernels' quotient by a row-wide divisor = one multiply + four fmas on the correctly rounded
+    reciprocal; must equal the IEEE division the reference does (src/main.rs:799, 763-765, 779) bit for bit.  4 M operand pairs: f32-valued
+    dividends (the exps), dividends that put the quotient next to a rounding midpoint, divisors with all-ones significands and just above 1."""
+    rng = np.random.default_rng(20261004)
+    n = 1 << 22
+    b = np.where(rng.random(n) < 0.5, rng.uniform(1.0, 70000.0, n), np.floor(rng.uniform(1.0, 65793.0, n)))
+    ones = rng.random(n) < 0.15
+    b[ones] = np.ldexp(2.0 - (1 + rng.integers(0, 4, ones.sum())) * 2.0 ** -52, rng.integers(0, 17, ones.sum()))
+    near1 = rng.random(n) < 0.1
+    b[near1] = 1.0 + rng.random(near1.sum()) * 2.0 ** -rng.integers(1, 40, near1.sum()).astype(np.float64)
+    a = np.ldexp(rng.random(n), -rng.integers(0, 140, n)).astype(np.float32).astype(np.float64)
+    mid = rng.random(n) < 0.5
+    q = np.ldexp(1.0 + rng.random(mid.sum()), -rng.integers(0, 60, mid.sum()))
+    am = b[mid] * q                                                     # then walk a few ulps around: some of these quotients sit at midpoints
+    am = am.view(np.int64) + rng.integers(-2, 3, mid.sum())
+    a[mid] = am.view(np.float64)
+    a[:6] = [0.0, 1.0, 2.0 ** -149, 1.862645149230957e-09, b[4], np.nextafter(b[5], 0.0)]
+    o = np.empty_like(a)
+    assert cz.lib().cz_debug_f64(4, a.ctypes.data, b.ctypes.data, o.ctypes.data, n) == 0
+    ref = a / b
+    bad = np.flatnonzero(o.view(np.uint64) != ref.view(np.uint64))
+    assert bad.size == 0, (bad[:5], a[bad[:5]], b[bad[:5]])
+
+
 @pytest.mark.parametrize("M,N,K,big", [(300, 576, 576, 1), (130, 128, 1536, 1), (1000, 960, 576, 1), (257, 3072, 576, 1), (64, 576, 1536, 1),
                                        (1, 576, 576, 0), (7, 960, 576, 0), (48, 576, 1536, 0), (64, 3072, 576, 0), (33, 512, 128, 0), (5, 49152, 576, 0)])
 def test_gemm_matches_canonical_fmaf_chain(cz, czo, M, N, K, big):
