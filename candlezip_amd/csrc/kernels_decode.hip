@@ -553,8 +553,11 @@ typedef __attribute__((address_space(1))) const float gfloat;     // K/V pointer
 // DA_MAXC = key chunks per wave: DA_WAVES * DA_MAXC chunks = the longest context of the instantiation (32 chunks = 2048 keys for the two
 // everyday shapes; 16 waves x 8 = 128 chunks = 8192 keys = max_position_embeddings of SmolLM2 for the long variant, whose chunk partials
 // of P.V are handed over in rounds of DA_WAVES chunks so that its LDS stays under 160 KB: scores 98 KB at rep 3).
+#ifndef CZ_DA_OCC
+#define CZ_DA_OCC 4          // waves per SIMD the whole-device form is compiled for (tuning build `make da_occ6`: 6 = three blocks per CU, 80 VGPRs)
+#endif
 template <int rep, int DA_WAVES, int DA_MAXC>
-__global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : 4)) void dec_attn_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
+__global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : (DA_WAVES == 8 ? CZ_DA_OCC : 4))) void dec_attn_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
                                                               const cz_seq_desc* __restrict__ descs, int n_heads, int n_kv, int s_stride,
                                                               size_t kv_off, const int* __restrict__ pos_dev, int out_kq, int kv_div) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
