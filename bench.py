@@ -422,7 +422,7 @@ def main_rwkv7(args):
     if args.profile_tokens > 0:
         pt = min(args.profile_tokens, T)
         rng = np.random.default_rng(99)
-        short = [np.concatenate([[0], rng.integers(0, cfg.vocab, pt)]).astype(np.uint32) for _ in range(min(per_lane, S, 256))]       # (256 streams: the pass profiles/r03_passrwkv7_s256_t512_* were taken on)
+        short = [np.concatenate([[0], rng.integers(0, cfg.vocab, pt)]).astype(np.uint32) for _ in range(min(per_lane, S, 1024))]       # (the timed region's own group width; 1 024 streams x 256 tokens: the pass profiles/r03_passrwkv7_s1024_t256_* were taken on)
         sess.debug_set("no_graph", 1)
         sess.profile_enable(True)
         pairs = sess.encode_tokens_batch(short)
@@ -458,7 +458,7 @@ def main_rwkv7(args):
             r.update({"traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": tnote, "kernel": kernel, "family": fam,
                       "algorithmic_per_launch": round((st["flops"] if bound == "mfma" else st["bytes"]) / n), "algorithmic_unit": "flop" if bound == "mfma" else "bytes",
                       "launches": st["launches"], "avg_launch_us": round(1e3 * ms / n, 3), "avg_kernel_us_rocprof": rp_us, "avg_kernel_us_rocprof_source": rp_src,
-                      "total_ms": round(ms, 2), "measured_in": f"eager per-family pass inside bench.py ({min(per_lane, S, 256)} streams x {min(args.profile_tokens, T)} tokens, one lane)"})
+                      "total_ms": round(ms, 2), "measured_in": f"eager per-family pass inside bench.py ({min(per_lane, S, 1024)} streams x {min(args.profile_tokens, T)} tokens, one lane)"})
             if rp_us:
                 alg = (st["flops"] if bound == "mfma" else st["bytes"]) / n
                 r["achieved_rocprof"] = round(alg / (rp_us * 1e-6) / (1e12 if bound == "mfma" else 1e9), 3)
@@ -519,7 +519,7 @@ def main():
     # rwkv7 = 1024 streams x 2048 tokens per step in ONE lock-step group (the wide step's GEMMs fill the device best at 1024 rows: 179 k tokens/s
     # decompress against 168 k for 2 x 256, profiles/r03_rwkv7_lane_shapes_final.jsonl), 3 steps
     dflt = {"smollm": dict(steps=17, streams=1024, lanes=2, lane_streams=512, sample_tokens=17408, profile_tokens=2048),
-            "rwkv7": dict(steps=3, streams=1024, lanes=1, lane_streams=1024, sample_tokens=2048, profile_tokens=512)}[args.backend]
+            "rwkv7": dict(steps=3, streams=1024, lanes=1, lane_streams=1024, sample_tokens=2048, profile_tokens=256)}[args.backend]
     for k, v in dflt.items():
         if getattr(args, k) is None:
             setattr(args, k, v)

@@ -9,7 +9,7 @@ smollm: one lock-step group of `--streams` (512) streams x `--tokens` (2048) tok
 the encode of all streams, then the lock-step decode — eager launches, one host synchronisation per decode step (library knob step_sync: the
 profiler serialises dispatches, a deep queue makes it crawl).  tools/prof_summary.py --skip-frac 0.25 then drops every kernel's first quarter of
 dispatches: for the decode-step kernels that is the ramp-up 1 -> 512 keys, what is left is the steady-state sawtooth 511 -> 1023 bench.py's timed
-region lives in.  rwkv7: `--streams` (256) streams x `--tokens` (512) tokens: sequence-parallel encode, then the lock-step decode.
+region lives in.  rwkv7: `--streams` (1024: the bench's group width) streams x `--tokens` (256) tokens: sequence-parallel encode, then the lock-step decode.
 No torch is imported: the process loads ONE ROCm runtime (the one libcandlezip_hip.so links).  A heartbeat line goes to stderr every 30 s."""
 import argparse
 import os
@@ -44,7 +44,7 @@ def main():
         cfg = cz.smollm2_135m_config()
         s = cz.Session("smollm", cfg, seed=0x5EED, embed_std=0.02, max_streams=S)
     else:
-        S, T = a.streams or 256, a.tokens or 512
+        S, T = a.streams or 1024, a.tokens or 256
         cfg = cz.rwkv7_0b1_config()
         s = cz.Session("rwkv7", cfg, seed=0x5EED, embed_std=0.02, max_streams=S)
     s.debug_set("max_lanes", 1); s.debug_set("no_graph", 1); s.debug_set("step_sync", 1)
