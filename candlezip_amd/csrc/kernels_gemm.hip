@@ -233,10 +233,12 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const float* __restric
     }
 }
 
+int g_gemm_lds_kb = 0;          // cz_debug_set "gemm_lds_kb": dynamic LDS per block of the big-M GEMM at least this many KB (0 = what the tiles need)
 template <int BM, int BN, int WM, int WN, int EPI = 0>
 static hipError_t launch_big(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R,
                              int ldr, int M, int N, int K, const unsigned char* row_mask = nullptr) {
-    const size_t smem = (size_t)(BM + BN) * LDK * sizeof(float);
+    size_t smem = (size_t)(BM + BN) * LDK * sizeof(float);
+    if ((size_t)g_gemm_lds_kb * 1024 > smem) smem = (size_t)g_gemm_lds_kb * 1024;      // tuning knob: fewer GEMM blocks per CU (room for another job's blocks beside them)
     auto kern = gemm_bf16w_kernel<BM, BN, WM, WN, EPI>;        // (its LDS limit is raised by cz_gemm_prepare, once per device at session open)
     const int nbx = N / BN, nby = (M + BM - 1) / BM, nblocks = nbx * nby;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, st, A, lda, W, C, ldc, R, ldr, M, N, K, nbx, nblocks, row_mask);
@@ -245,8 +247,7 @@ static hipError_t launch_big(hipStream_t st, const float* A, int lda, const uint
 
 template <int BM, int BN, int EPI>
 static hipError_t big_prepare() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16w_kernel<BM, BN, 2, 2, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)((size_t)(BM + BN) * LDK * sizeof(float)));
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16w_kernel<BM, BN, 2, 2, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // (the tiles need (BM + BN) * LDK * 4; the rest is for the gemm_lds_kb knob)
 }
 // per device, at session open: dynamic-LDS limits of every instantiation the launchers below use (a lazily set process-wide flag would
 // leave a second device's kernels at the 48 KB default and race between the host threads of the decode lanes)

@@ -23,6 +23,7 @@
 #include "cz_kernels.h"
 #include "cz_session.h"
 
+extern int g_gemm_lds_kb;
 extern int g_attn_v1;
 extern int g_dec_grid_target;
 extern int g_dec_nw_cap;
@@ -1518,6 +1519,7 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "dec_wide_rows")) g_dec_wide_rows = (int)value;
     else if (!strcmp(key, "dec_attn_small_grid")) g_dec_attn_small_grid = (int)value;
     else if (!strcmp(key, "dec_attn_split_max")) g_dec_attn_split_max = (int)value;
+    else if (!strcmp(key, "gemm_lds_kb")) g_gemm_lds_kb = (int)value < 0 ? 0 : ((int)value > 160 ? 160 : (int)value);   // (process-wide) fewer big-M GEMM blocks per CU
     else if (!strcmp(key, "dbg_skip")) s->dbg_skip = (int)value;          // tools/bench_decode_step.py: 1 = no attention, 2 = no GEMMs/norms (timing only; results are garbage)
     else if (!strcmp(key, "fuse_norm")) s->fuse_norm = (int)value;
     else if (!strcmp(key, "dec_norm_mfma")) g_dec_norm_mfma = (int)value;
