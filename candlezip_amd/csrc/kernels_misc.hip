@@ -84,44 +84,56 @@ __global__ __launch_bounds__(256) void rmsnorm_small_kernel(const float* __restr
     __shared__ float xs[RS_ROWS * RS_ROW];
     __shared__ float part[RS_ROWS][17];
     __shared__ float mv[RS_ROWS];
-    const int tid = threadIdx.x, per_row = d / 4, nch = d / 64, m0 = blockIdx.x * RS_ROWS;
-    for (int i = tid; i < RS_ROWS * per_row; i += 256) {
-        const int rr = i / per_row, cc = i % per_row;
-        if (m0 + rr >= M) break;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(X + (size_t)(m0 + rr) * ldx + cc * 4);
-        float* dst = xs + rr * RS_ROW + (cc >> 4) * RS_CH + (cc & 15) * 4;
-        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+    // wave r of the block owns row m0 + r: no index arithmetic with divisions, and every global operand — the row AND the weights the
+    // last phase needs — is requested before the first barrier (this kernel sits 61 times in the dependent chain of a wide decode step)
+    const int tid = threadIdx.x, lane = tid & 63, r = tid >> 6, per_row = d / 4, nch = d / 64, m0 = blockIdx.x * RS_ROWS;
+    const int row = m0 + r < M ? m0 + r : M - 1;                     // (clamped address, never a conditional load; the store below is guarded)
+    const bool live = m0 + r < M;
+    f32x4 v[4]; uint2 wb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cc = lane + 64 * j, ca = cc < per_row ? cc : per_row - 1;
+        v[j] = *reinterpret_cast<const f32x4*>(X + (size_t)row * ldx + ca * 4);
+        wb[j] = *reinterpret_cast<const uint2*>(w + ca * 4);
     }
-    __syncthreads();
-    if (tid < RS_ROWS * 16) {
-        const int r = tid >> 4, c = tid & 15;
-        if (m0 + r < M && c < nch) {
-            const float* src = xs + r * RS_ROW + c * RS_CH;
-            float p = 0.0f;
-#pragma unroll 16
-            for (int k = 0; k < 64; ++k) { const float q = src[k] * src[k]; p = p + q; }
-            part[r][c] = p;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cc = lane + 64 * j;
+        if (cc < per_row) {
+            float* dst = xs + r * RS_ROW + (cc >> 4) * RS_CH + (cc & 15) * 4;
+            dst[0] = v[j][0]; dst[1] = v[j][1]; dst[2] = v[j][2]; dst[3] = v[j][3];
         }
     }
     __syncthreads();
-    if (tid < RS_ROWS && m0 + tid < M) {
+    if (tid < RS_ROWS * 16) {
+        const int rr = tid >> 4, c = tid & 15;
+        if (c < nch) {
+            const float* src = xs + rr * RS_ROW + c * RS_CH;
+            float p = 0.0f;
+#pragma unroll 16
+            for (int k = 0; k < 64; ++k) { const float q = src[k] * src[k]; p = p + q; }
+            part[rr][c] = p;
+        }
+    }
+    __syncthreads();
+    if (tid < RS_ROWS) {
         float t = part[tid][0];
         for (int k = 1; k < nch; ++k) t = t + part[tid][k];
         mv[tid] = sqrtf(t / (float)d + eps);
     }
     __syncthreads();
-    for (int i = tid; i < RS_ROWS * per_row; i += 256) {
-        const int rr = i / per_row, cc = i % per_row;
-        if (m0 + rr >= M) break;
-        const float* src = xs + rr * RS_ROW + (cc >> 4) * RS_CH + (cc & 15) * 4;
-        const uint2 wb = *reinterpret_cast<const uint2*>(w + cc * 4);
-        const float mval = mv[rr];
-        f32x4 o;
-        o[0] = src[0] / mval * cz_bits_f32(wb.x << 16);
-        o[1] = src[1] / mval * cz_bits_f32(wb.x & 0xffff0000u);
-        o[2] = src[2] / mval * cz_bits_f32(wb.y << 16);
-        o[3] = src[3] / mval * cz_bits_f32(wb.y & 0xffff0000u);
-        *reinterpret_cast<f32x4*>(Y + (size_t)(m0 + rr) * ldy + cc * 4) = o;
+    const float mval = mv[r];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cc = lane + 64 * j;
+        if (cc < per_row && live) {
+            f32x4 o;
+            o[0] = v[j][0] / mval * cz_bits_f32(wb[j].x << 16);
+            o[1] = v[j][1] / mval * cz_bits_f32(wb[j].x & 0xffff0000u);
+            o[2] = v[j][2] / mval * cz_bits_f32(wb[j].y << 16);
+            o[3] = v[j][3] / mval * cz_bits_f32(wb[j].y & 0xffff0000u);
+            *reinterpret_cast<f32x4*>(Y + (size_t)row * ldy + cc * 4) = o;
+        }
     }
 }
 hipError_t cz_launch_rmsnorm(hipStream_t st, const float* X, int ldx, const uint16_t* w, float* Y, int ldy, int M, int d, float eps,
