@@ -553,6 +553,9 @@ typedef __attribute__((address_space(1))) const float gfloat;     // K/V pointer
 // DA_MAXC = key chunks per wave: DA_WAVES * DA_MAXC chunks = the longest context of the instantiation (32 chunks = 2048 keys for the two
 // everyday shapes; 16 waves x 8 = 128 chunks = 8192 keys = max_position_embeddings of SmolLM2 for the long variant, whose chunk partials
 // of P.V are handed over in rounds of DA_WAVES chunks so that its LDS stays under 160 KB: scores 98 KB at rep 3).
+#ifndef CZ_DA_VPRE
+#define CZ_DA_VPRE 1         // the whole-device form requests its first V round before the softmax phases (tuning build `make da_vpre0`: 0 = not)
+#endif
 #ifndef CZ_DA_OCC
 #define CZ_DA_OCC 4          // waves per SIMD the whole-device form is compiled for (tuning build `make da_occ6`: 6 = three blocks per CU, 80 VGPRs)
 #endif
@@ -642,14 +645,17 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : (DA_WAVES == 8 ? 
     DST(3, 2);                                  // phase 1: K streamed, scores
     // DEEP: the V slab of the wave's first chunk is requested NOW — the K registers are free — and arrives under the two softmax phases and their
     // barriers (the bit pattern of what is loaded does not depend on them); phase 3 then starts on resident data
-    float vpre[DEEP ? 64 : 1];
-    if (DEEP) {
+    // The whole-device form (two blocks per CU) requests the first 16-key round of that slab: enough to keep loads in flight through the softmax
+    // phases, whose barriers otherwise leave this block's share of the memory pipe empty (CZ_DA_VPRE = 0: off)
+    constexpr int VPRE = DEEP ? 64 : ((!LONG && DA_WAVES == 8 && CZ_DA_VPRE) ? 16 : 0);
+    float vpre[VPRE ? VPRE : 1];
+    if (VPRE) {
         const int c = wave;
         if (c < nch) {
             const int jend = nk - c * 64 < 64 ? nk - c * 64 : 64;
             gfloat* vp = Vb + (size_t)(c * 64) * sd.kv_stride + lane;
 #pragma unroll
-            for (int jx = 0; jx < 64; ++jx) { const int jj = jx < jend ? jx : jend - 1; vpre[DEEP ? jx : 0] = __builtin_nontemporal_load(vp + (size_t)jj * sd.kv_stride); }
+            for (int jx = 0; jx < (VPRE ? VPRE : 1); ++jx) { const int jj = jx < jend ? jx : jend - 1; vpre[VPRE ? jx : 0] = __builtin_nontemporal_load(vp + (size_t)jj * sd.kv_stride); }
         }
     }
     if (lane == 0) {
@@ -723,9 +729,9 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : (DA_WAVES == 8 ? 
             // for each one.  Keys past nk have p == 0 (exp(-inf)) and v == 0: fma(0, 0, acc) == acc, so the chain needs no guard.
             auto v_round = [&](const int g) {
                 float vreg[16];
-                if (DEEP && i == 0) {
+                if (VPRE && i == 0 && g * 16 < VPRE) {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) vreg[j] = vpre[DEEP ? g * 16 + j : 0];
+                    for (int j = 0; j < 16; ++j) vreg[j] = vpre[VPRE ? (g * 16 + j) % (VPRE ? VPRE : 1) : 0];
                 } else {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) { const int jx = g * 16 + j; const int jj = jx < jend ? jx : jend - 1; vreg[j] = __builtin_nontemporal_load(vp + (size_t)jj * sd.kv_stride); }
