@@ -455,14 +455,20 @@ def main_rwkv7(args):
                 r = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5)}
             traffic, tnote = pmc_traffic(prefix, "rwkv7")
             rp_us, rp_src = rocprof_avg_us(prefix, "rwkv7")
+            if prefix.startswith("gemm_bf16w_kernel"):            # (launches of several shapes and epilogues: no per-launch comparison with the kernel-trace CSV)
+                rp_us, rp_src = None, "not comparable per launch (launches of several shapes; the kernel-trace CSV holds the totals)"
             r.update({"traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": tnote, "kernel": kernel, "family": fam,
                       "algorithmic_per_launch": round((st["flops"] if bound == "mfma" else st["bytes"]) / n), "algorithmic_unit": "flop" if bound == "mfma" else "bytes",
                       "launches": st["launches"], "avg_launch_us": round(1e3 * ms / n, 3), "avg_kernel_us_rocprof": rp_us, "avg_kernel_us_rocprof_source": rp_src,
                       "total_ms": round(ms, 2), "measured_in": f"eager per-family pass inside bench.py ({min(per_lane, S, 1024)} streams x {min(args.profile_tokens, T)} tokens, one lane)"})
-            if rp_us:
+            if rp_us and st["launches"]:
                 alg = (st["flops"] if bound == "mfma" else st["bytes"]) / n
                 r["achieved_rocprof"] = round(alg / (rp_us * 1e-6) / (1e12 if bound == "mfma" else 1e9), 3)
                 r["frac_rocprof"] = round(r["achieved_rocprof"] / (FP32_MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS), 4)
+            if not st["launches"]:                                # --profile-tokens 0: nothing was measured; say so instead of printing zeros
+                for k in ("achieved", "frac", "algorithmic_per_launch", "avg_launch_us", "total_ms"):
+                    r[k] = None
+                r["measured_in"] = "not measured: the per-family pass was skipped (--profile-tokens 0)"
             return r
         line = {
             "metric": "tokens/sec, Canterbury-style self-test (compress+decompress), rwkv7",
@@ -645,15 +651,21 @@ def main():
             traffic, tnote = pmc_traffic(prefix, args.profile_tokens)
             n = max(st["launches"], 1)
             rp_us, rp_src = rocprof_avg_us(prefix, args.profile_tokens)
+            if fn.startswith("gemm_bf16w_kernel"):                # its launches are not one shape: the batches of this pass (encode as a RANGE, whole re-primes) are cut differently from
+                rp_us, rp_src = None, "not comparable per launch: tools/profile_pass.py cuts the same rows into other batches (the kernel-trace CSV holds its totals)"   # the profiled pass's
             r.update({"traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": tnote, "kernel": fn + " (all instantiations)", "families": fams,
                       "algorithmic_per_launch": round((st["flops"] if bound == "mfma" else st["bytes"]) / n), "algorithmic_unit": "flop" if bound == "mfma" else "bytes",
                       "launches": st["launches"], "avg_launch_us": round(1e3 * ms / n, 3),
                       "avg_launch_us_note": "HIP events around each launch on the library's stream: kernel + launch gap; `achieved` is computed from this figure",
                       "avg_kernel_us_rocprof": rp_us, "avg_kernel_us_rocprof_source": rp_src, "total_ms": round(ms, 2), "measured_in": where})
-            if rp_us:
+            if rp_us and st["launches"]:
                 alg = (st["flops"] if bound == "mfma" else st["bytes"]) / n
                 r["achieved_rocprof"] = round(alg / (rp_us * 1e-6) / (1e12 if bound == "mfma" else 1e9), 3)
                 r["frac_rocprof"] = round(r["achieved_rocprof"] / (FP32_MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS), 4)
+            if not st["launches"]:                                # --profile-tokens 0: nothing was measured; say so instead of printing zeros
+                for k in ("achieved", "frac", "algorithmic_per_launch", "avg_launch_us", "total_ms"):
+                    r[k] = None
+                r["measured_in"] = "not measured: the per-family pass was skipped (--profile-tokens 0)"
             return r
 
         if per_lane >= 256:      # wide lock-step groups: the layer projections run on gemm_mid_kernel, lm_head and the norms on the big-M kernels
