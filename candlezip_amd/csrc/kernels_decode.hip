@@ -684,15 +684,15 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : (DA_WAVES == 8 ? 
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0xc07f);                 // this wave's LDS writes are visible to its own lanes
-#pragma unroll
-    for (int i = 0; i < DA_MAXC; ++i) {
-        const int c = wave + DA_WAVES * i;
-        if (c < nch && lane < rep) {
-            const float* p = S + lane * s_stride + c * 64;
+    {   // one lane per (chunk of this wave, head): the wave's DA_MAXC x rep chains of 64 adds run side by side (they used to run one after the
+        // other on `rep` lanes: 4 x 64 dependent adds between the two barriers of the softmax, with no load of this block in flight)
+        const int i = lane / DA_MAXREP, h = lane % DA_MAXREP, c = wave + DA_WAVES * i;
+        if (lane < DA_MAXC * DA_MAXREP && h < rep && c < nch) {
+            const float* p = S + h * s_stride + c * 64;
             float acc = 0.0f;
 #pragma unroll 16
             for (int k = 0; k < 64; ++k) acc = acc + p[k];
-            csum[lane * CS + c] = acc;
+            csum[h * CS + c] = acc;
         }
     }
     __syncthreads();
