@@ -62,8 +62,9 @@ hipError_t cz_launch_cdf_pairs(hipStream_t st, const float* logits, int ld, cons
                                int rows, int vocab, int mode, unsigned* fallback_count, double* scratch,
                                const unsigned long long* out_step_dev = nullptr);   // non-null: pairs go to c_lo/c_hi + *out_step_dev * rows
 // floor-softmax probability of sym[row] (f64) for the cross-entropy span scorer (src/main.rs:1725-1751, 758-766)
+// mode 0: softmax_pdf_floor(logits)[sym] (the generic cross_entropy_bits_over_span); mode 1: combined_pdf_with_literals(logits)[sym] (..._rwkv)
 hipError_t cz_launch_xe_probs(hipStream_t st, const float* logits, int ld, const uint32_t* sym, double* p_out, int rows, int vocab, unsigned* fallback_count,
-                              double* scratch);
+                              double* scratch, int mode = 0);
 #define CZ_CDF_PAR_MAX_GRID 1024
 size_t cz_cdf_par_scratch_bytes(int vocab, int mode);     // the `scratch` the exact-parallel CDF launchers need (owned by the session)
 hipError_t cz_launch_cdf_pairs_serial(hipStream_t st, const float* logits, int ld, const uint32_t* sym, uint32_t* c_lo, uint32_t* c_hi,

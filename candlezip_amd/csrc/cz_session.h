@@ -112,6 +112,8 @@ cz_status cz_rwkv7_step_host(cz_session* s, uint32_t token, float* out_logits);
 cz_status cz_rwkv7_reprime_host(cz_session* s, const uint32_t* hist, size_t n, float* out_logits);
 cz_status cz_rwkv7_make_lane(const cz_session* parent, cz_session* child);
 cz_status cz_rwkv7_encode_seq(cz_session* s, size_t n_streams, const uint32_t* const* ids, const size_t* n, uint32_t* const* lo, uint32_t* const* hi);
+cz_status cz_rwkv7_xe_bits(cz_session* s, size_t n_spans, const uint32_t* const* hist, const size_t* n_hist, const uint32_t* const* hint, const size_t* n_hint,
+                           const uint32_t* const* targets, const size_t* n_targets, double* bits_out);
 cz_status cz_rwkv7_encode_group(cz_session* s, int B, const uint32_t* const* ids, const size_t* n, uint32_t* const* lo, uint32_t* const* hi);
 cz_status cz_rwkv7_decode_begin(cz_session* s, int B, const uint8_t* const* payloads, const size_t* lens, const size_t* caps, const size_t* tcs, uint32_t bos);
 // session.hip: payload buffer / decoder states of a lock-step group, shared by both back-ends

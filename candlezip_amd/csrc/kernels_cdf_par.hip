@@ -525,12 +525,93 @@ __global__ __launch_bounds__(T_PAR) void xe_prob_kernel(const float* __restrict_
         __syncthreads();
     }
 }
+// The same for the RWKV branch (cross_entropy_bits_over_span_rwkv, src/main.rs:1753-1787): p = combined_pdf_with_literals(logits)[sym] — the three
+// sequential chains of cdf_par_kernel's MODE 1 (sum of exps over V, sum of floored probabilities over V, sum of the scaled distribution with its 256
+// literal entries over V + 256), then the one entry; sym >= V + 256 -> ac_p_min() (`if idx < pdf.len() { pdf[idx] } else { ac_p_min() }`, :1779-1780).
+template <int LMAX>
+__global__ __launch_bounds__(T_PAR) void xe_prob_lit_kernel(const float* __restrict__ logits, int ld, int rows, int V, const uint32_t* __restrict__ sym,
+                                                            double* __restrict__ p_out, double* __restrict__ scratch_all, unsigned* __restrict__ fallback_count) {
+    __shared__ par_smem_t<LMAX> sm;
+    const int n = V + 256;
+    double* scratch = scratch_all + (size_t)blockIdx.x * n;
+    int L = (n + T_PAR - 1) / T_PAR;
+    if (L >= 8) L = (L + 3) & ~3;
+    unsigned long long ph_t = 0;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int tid = launder((int)threadIdx.x), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int first = tid * L;
+        const int cntA = first >= V ? 0 : (V - first < L ? V - first : L);       // owned vocabulary entries
+        const int cnt = first >= n ? 0 : (n - first < L ? n - first : L);        // owned symbols (vocabulary, then literals)
+        const float* l = logits + (size_t)row * ld;
+        if (tid == 0) { sm.flag = 0; sm.L = L; sm.n = V; }
+        float ef[LMAX];
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < LMAX; ++k) ef[k] = l[first + k < V ? first + k : V - 1];      // (unconditional clamped loads, as in cdf_par_kernel)
+#pragma unroll
+        for (int k = 0; k < LMAX; ++k) if (k < cntA && ef[k] > m) m = ef[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { float y = shfl_xor_f(m, o, lane); m = y > m ? y : m; }
+        if (lane == 0) sm.redf[wave] = m;
+        __syncthreads();
+        m = sm.redf[0];
+#pragma unroll
+        for (int w = 1; w < NWAVE; ++w) m = sm.redf[w] > m ? sm.redf[w] : m;
+        __syncthreads();
+        double csum_e = 0.0;
+#pragma unroll
+        for (int k = 0; k < LMAX; ++k) if (k < cntA) { ef[k] = cz_expf(ef[k] - m); csum_e += (double)ef[k]; }
+        const double sum = exact_seq_sum<LMAX>([&](int k) { return (double)ef[k]; }, csum_e, cntA, first, sm, scratch, false, nullptr, ph_t, tid);
+        bool fallback = sm.flag != 0 || !(sum > 0.0);
+        const double inv_sum = 1.0 / sum;
+        double norm = 1.0, inv_norm = 1.0, sum2 = 0.0;
+        const double p_escape_total = 256.0 * P_MIN;             // :771
+        const double scale = (1.0 - p_escape_total) > 0.0 ? (1.0 - p_escape_total) : 0.0;
+        const double lit = p_escape_total > 0.0 ? p_escape_total / 256.0 : 0.0;
+        auto fl = [&](int k) { const double p = div_by((double)ef[k], sum, inv_sum); return p > P_MIN ? p : P_MIN; };
+        auto mix = [&](int k) { return k < cntA ? div_by(fl(k), norm, inv_norm) * scale : lit; };
+        if (!fallback) {
+            double cs = 0.0;
+#pragma unroll
+            for (int k = 0; k < LMAX; ++k) if (k < cntA) { const double p = (double)ef[k] * inv_sum; cs += p > P_MIN ? p : P_MIN; }
+            norm = exact_seq_sum<LMAX>(fl, cs, cntA, first, sm, scratch, false, nullptr, ph_t, tid);
+            fallback = sm.flag != 0 || !(norm > 0.0);
+            if (!fallback) {
+                if (tid == 0) sm.n = n;                          // the last chain runs over vocabulary + literals
+                inv_norm = 1.0 / norm;
+                const double cs2 = cs * (scale / norm) + (double)(cnt - cntA) * lit;
+                sum2 = exact_seq_sum<LMAX>(mix, cs2, cnt, first, sm, scratch, false, nullptr, ph_t, tid);
+                fallback = sm.flag != 0;
+            }
+        }
+        const uint32_t s = sym[row];
+        if (fallback) {
+            if (tid == 0) {
+                if (fallback_count) atomicAdd(fallback_count, 1u);
+                pdf_ctx c;
+                pdf_prepare(c, l, V, 1);
+                p_out[row] = s < (uint32_t)n ? pdf_at(c, (int)s) : P_MIN;
+            }
+        } else {
+            if (s >= (uint32_t)n) { if (tid == 0) p_out[row] = P_MIN; }
+            else if (s >= (uint32_t)first && s < (uint32_t)(first + cnt)) {
+                double p = 0.0;
+#pragma unroll
+                for (int k = 0; k < LMAX; ++k)
+                    if (first + k == (int)s) { const double x = mix(k); p = sum2 > 0.0 ? x / sum2 : x; }      // :779 (one division per row: the plain IEEE one)
+                p_out[row] = p;
+            }
+        }
+        __syncthreads();
+    }
+}
 hipError_t cz_launch_xe_probs(hipStream_t st, const float* logits, int ld, const uint32_t* sym, double* p_out, int rows, int vocab, unsigned* fallback_count,
-                              double* scratch) {
+                              double* scratch, int mode) {
     if (rows <= 0) return hipSuccess;
-    if (!scratch || vocab > T_PAR * LMAX_RWKV) return hipErrorInvalidValue;
+    if (!scratch || vocab + (mode ? 256 : 0) > T_PAR * LMAX_RWKV) return hipErrorInvalidValue;
     const int grid = rows < CZ_CDF_PAR_MAX_GRID ? rows : CZ_CDF_PAR_MAX_GRID;
-    if (vocab <= T_PAR * LMAX_SMOLLM) hipLaunchKernelGGL((xe_prob_kernel<LMAX_SMOLLM>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, p_out, scratch, fallback_count);
+    if (mode) hipLaunchKernelGGL((xe_prob_lit_kernel<LMAX_RWKV>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, p_out, scratch, fallback_count);
+    else if (vocab <= T_PAR * LMAX_SMOLLM) hipLaunchKernelGGL((xe_prob_kernel<LMAX_SMOLLM>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, p_out, scratch, fallback_count);
     else hipLaunchKernelGGL((xe_prob_kernel<LMAX_RWKV>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows, vocab, sym, p_out, scratch, fallback_count);
     return hipGetLastError();
 }

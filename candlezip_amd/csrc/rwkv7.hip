@@ -934,10 +934,14 @@ __global__ __launch_bounds__(64) void rw_seq_post_kernel(const float* __restrict
     OUT[(size_t)r * C + c] = (gn + ad) * g;
 }
 
+static const double P_MIN_HOST = 1.862645149230957e-09;      // ac_p_min() = 2 * 2^-30 (src/main.rs:235-238; P_MIN of cz_cdf_common.h)
 int g_rw_seq_rows = 32768;     // tuning knob (cz_debug_set "rwkv_seq_rows"): rows (model steps of all streams) per time block of the sequence-parallel encode
 
 // Streams [0, B) of one group (B <= max_streams: the recurrent state arrays have that many slots).  Coder intervals straight into lo / hi.
-static cz_status rw_encode_seq_group(cz_session* s, int B, const uint32_t* const* ids, const size_t* n, uint32_t* const* lo, uint32_t* const* hi) {
+// xe form (first_sym / p_out given): only the coded symbols i >= first_sym[b] are evaluated, and what comes back is the probability
+// combined_pdf_with_literals gives each of them (p_out[b][i - first_sym[b]]) instead of its coder interval.
+static cz_status rw_encode_seq_group(cz_session* s, int B, const uint32_t* const* ids, const size_t* n, uint32_t* const* lo, uint32_t* const* hi,
+                                     const size_t* first_sym = nullptr, double* const* p_out = nullptr) {
     Rwkv7Model* m = s->rwkv; const cz_rwkv7_config& c = m->cfg;
     const uint32_t V = (uint32_t)c.vocab;
     const int C = c.hidden, F = c.d_ffn, H = C / 64, Bc = s->max_streams, L = c.n_layers;
@@ -980,7 +984,8 @@ static cz_status rw_encode_seq_group(cz_session* s, int B, const uint32_t* const
             const int b = s_stream[k];
             size_t& i = sym_cur[b];
             while (i + 1 < n[b] && rowof[b][i] < t0 + (size_t)s_len[k]) {
-                crow.push_back(s_row0[k] + (int)(rowof[b][i] - t0)); csym.push_back(ids[b][i + 1]); cdst.push_back({b, i}); ++i;
+                if (!first_sym || i >= first_sym[b]) { crow.push_back(s_row0[k] + (int)(rowof[b][i] - t0)); csym.push_back(ids[b][i + 1]); cdst.push_back({b, i}); }
+                ++i;
             }
         }
         const size_t Lr = crow.size();
@@ -1062,7 +1067,7 @@ static cz_status rw_encode_seq_group(cz_session* s, int B, const uint32_t* const
             HIPCHK(gemm(FFK, F, y.fv_n, X, C, X, C, F));                                                                 // x = x + ffn
         }
         // logits of the coded symbols' rows -> coder intervals (combined_pdf_with_literals + inline quantiser, src/main.rs:2303-2325)
-        CZCHK(s->clo.ensure(Lr * 4 + 16)); CZCHK(s->chi.ensure(Lr * 4 + 16));
+        CZCHK(s->clo.ensure(Lr * (p_out ? 8 : 4) + 16)); CZCHK(s->chi.ensure(Lr * 4 + 16));
         const size_t LB = std::max<size_t>(1, std::min(s->logit_batch_rows, (size_t)(1ull << 31) / ((size_t)c.vocab * 4)));
         CZCHK(s->logits.ensure(std::min(LB, std::max<size_t>(Lr, 1)) * (size_t)c.vocab * 4)); CZCHK(m->q_xn.ensure(std::min(LB, std::max<size_t>(Lr, 1)) * (size_t)C * 4));
         for (size_t r0 = 0; r0 < Lr; r0 += LB) {
@@ -1075,16 +1080,19 @@ static cz_status rw_encode_seq_group(cz_session* s, int B, const uint32_t* const
             HIPCHK(cz_launch_gemm(st, (const float*)m->q_xn.p, C, m->head_n, (float*)s->logits.p, c.vocab, nullptr, 0, nr, c.vocab, C, 0));
             s->prof_end(2.0 * nr * (double)c.vocab * C, (double)c.vocab * C * 2 + (double)nr * (c.vocab + C) * 4);
             s->prof_begin(PK_CDF);
-            HIPCHK(cz_launch_cdf_pairs(st, (const float*)s->logits.p, c.vocab, d_csym + r0, (uint32_t*)s->clo.p + r0, (uint32_t*)s->chi.p + r0, nr, c.vocab, 1, s->fallback_dev, s->cdf_scratch));
+            if (p_out) HIPCHK(cz_launch_xe_probs(st, (const float*)s->logits.p, c.vocab, d_csym + r0, (double*)s->clo.p + r0, nr, c.vocab, s->fallback_dev, s->cdf_scratch, 1));
+            else HIPCHK(cz_launch_cdf_pairs(st, (const float*)s->logits.p, c.vocab, d_csym + r0, (uint32_t*)s->clo.p + r0, (uint32_t*)s->chi.p + r0, nr, c.vocab, 1, s->fallback_dev, s->cdf_scratch));
             s->prof_end(0, (double)nr * c.vocab * 4);
         }
-        std::vector<uint32_t> hlo(Lr), hhi(Lr);
-        if (Lr) {
+        std::vector<uint32_t> hlo(p_out ? 0 : Lr), hhi(p_out ? 0 : Lr); std::vector<double> hp(p_out ? Lr : 0);
+        if (Lr && p_out) HIPCHK(hipMemcpyAsync(hp.data(), s->clo.p, Lr * 8, hipMemcpyDeviceToHost, st));
+        else if (Lr) {
             HIPCHK(hipMemcpyAsync(hlo.data(), s->clo.p, Lr * 4, hipMemcpyDeviceToHost, st));
             HIPCHK(hipMemcpyAsync(hhi.data(), s->chi.p, Lr * 4, hipMemcpyDeviceToHost, st));
         }
         HIPCHK(hipStreamSynchronize(st));                                   // (the block's host index vectors go out of scope)
-        for (size_t r = 0; r < Lr; ++r) { lo[cdst[r].b][cdst[r].i] = hlo[r]; hi[cdst[r].b][cdst[r].i] = hhi[r]; }
+        if (p_out) for (size_t r = 0; r < Lr; ++r) p_out[cdst[r].b][cdst[r].i - first_sym[cdst[r].b]] = hp[r];
+        else for (size_t r = 0; r < Lr; ++r) { lo[cdst[r].b][cdst[r].i] = hlo[r]; hi[cdst[r].b][cdst[r].i] = hhi[r]; }
     }
     return CZ_OK;
 }
@@ -1096,6 +1104,52 @@ cz_status cz_rwkv7_encode_seq(cz_session* s, size_t n_streams, const uint32_t* c
         CZCHK(rw_encode_seq_group(s, B, ids + g0, n + g0, lo + g0, hi + g0));
     }
     s->index_pos = 0;
+    return CZ_OK;
+}
+
+// cross_entropy_bits_over_span_rwkv (src/main.rs:1753-1787), batched over spans: prime = history without its literal symbols ++ hint (max_context_length()
+// is usize::MAX for this session, src/models.rs:150: nothing is cut); state reset; the prime fed token by token; then for every target
+// p = combined_pdf_with_literals(logits)[target] (ac_p_min() past its end), bits += -log2(max(p, 1e-300)), and the model steps only on vocabulary
+// targets.  On the device a span is ONE teacher-forced stream prime ++ targets through the sequence-parallel encode (the same rows, the same
+// logits as the token-by-token loop: reduction orders depend on K only), evaluated from its first target on.  log2 and the running sum: host libm.
+cz_status cz_rwkv7_xe_bits(cz_session* s, size_t n_spans, const uint32_t* const* hist, const size_t* n_hist, const uint32_t* const* hint, const size_t* n_hint,
+                           const uint32_t* const* targets, const size_t* n_targets, double* bits_out) {
+    const uint32_t V = (uint32_t)s->rwkv->cfg.vocab;
+    std::vector<std::vector<uint32_t>> ids(n_spans); std::vector<std::vector<double>> p(n_spans); std::vector<std::vector<size_t>> tix(n_spans);
+    std::vector<size_t> first(n_spans);
+    for (size_t k = 0; k < n_spans; ++k) {
+        bits_out[k] = 0.0;
+        const size_t nt = n_targets[k];
+        if (nt == 0) continue;                                                             // :1760
+        const size_t nh = n_hist ? n_hist[k] : 0, ng = n_hint ? n_hint[k] : 0;
+        for (size_t i = 0; i < nh; ++i) if (hist[k][i] < V) ids[k].push_back(hist[k][i]);  // "filter out literals from history" (:1764-1766)
+        for (size_t i = 0; i < ng; ++i) {
+            if (hint[k][i] >= V) { cz_set_error("span %zu: hint token %u >= vocab (the reference's embedding lookup fails there)", k, hint[k][i]); return CZ_ERR_ARG; }
+            ids[k].push_back(hint[k][i]);
+        }
+        if (ids[k].empty()) { cz_set_error("reprime called with empty history (rwkv xe)"); return CZ_ERR_ARG; }      // :1773
+        first[k] = ids[k].size() - 1;                                                      // coded symbol i = the one after ids[i]: the first target
+        for (size_t i = 0; i < nt; ++i)
+            if (targets[k][i] < V + 256) { ids[k].push_back(targets[k][i]); tix[k].push_back(i); }   // past the pdf's end: ac_p_min(), no step (:1779-1783)
+        p[k].assign(tix[k].size(), 0.0);
+    }
+    const size_t cap = (size_t)s->max_streams;
+    std::vector<size_t> live; for (size_t k = 0; k < n_spans; ++k) if (!tix[k].empty()) live.push_back(k);
+    for (size_t g0 = 0; g0 < live.size(); g0 += cap) {
+        const int B = (int)std::min(cap, live.size() - g0);
+        std::vector<const uint32_t*> ip(B); std::vector<size_t> in(B), fs(B); std::vector<double*> pp(B);
+        for (int b = 0; b < B; ++b) { const size_t k = live[g0 + b]; ip[b] = ids[k].data(); in[b] = ids[k].size(); fs[b] = first[k]; pp[b] = p[k].data(); }
+        CZCHK(rw_encode_seq_group(s, B, ip.data(), in.data(), nullptr, nullptr, fs.data(), pp.data()));
+    }
+    s->index_pos = 0;
+    for (size_t k = 0; k < n_spans; ++k) {
+        if (n_targets[k] == 0) continue;
+        std::vector<double> pt(n_targets[k], P_MIN_HOST);
+        for (size_t j = 0; j < tix[k].size(); ++j) pt[tix[k][j]] = p[k][j];
+        double bits = 0.0;
+        for (size_t i = 0; i < n_targets[k]; ++i) { double q = pt[i]; if (!(q > 1e-300)) q = 1e-300; bits += -log2(q); }
+        bits_out[k] = bits;
+    }
     return CZ_OK;
 }
 

@@ -1360,8 +1360,8 @@ extern "C" cz_status cz_xe_bits_batch(cz_session* s, size_t n_spans, const uint3
                                       const size_t* n_hint, const uint32_t* const* targets, const size_t* n_targets, double* bits_out) {
     if (cz_dead(s)) return CZ_ERR_STATE;
     if (!s || !targets || !n_targets || !bits_out || (n_history && !history) || (n_hint && !hint)) { cz_set_error("cz_xe_bits_batch: null argument"); return CZ_ERR_ARG; }
-    if (s->backend != CZ_BACKEND_SMOLLM) { cz_set_error("cz_xe_bits: only the smollm backend is supported (cross_entropy_bits_over_span_rwkv is not built)"); return CZ_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(s->device));
+    if (s->backend == CZ_BACKEND_RWKV7) return cz_rwkv7_xe_bits(s, n_spans, history, n_history, hint, n_hint, targets, n_targets, bits_out);   // cross_entropy_bits_over_span_rwkv
     return xe_llama(s, n_spans, history, n_history, hint, n_hint, targets, n_targets, bits_out);
 }
 extern "C" cz_status cz_xe_bits_over_span(cz_session* s, const uint32_t* history, size_t n_history, const uint32_t* hint, size_t n_hint,

@@ -133,7 +133,11 @@ cz_status cz_decode_end(cz_session* s);
  * prime = last min(511 - min(n_hint, 511), n_history) ids of history ++ first min(n_hint, 511) ids of hint; bits = sum over the targets of
  * -log2(max(p(target | prime, earlier targets), 1e-300)).  Teacher-forced and batched on the GPU (one causal forward per span, all spans
  * of a batch share the GEMMs); the session's single-stream state is left untouched.  Errors like the reference: empty prime ->
- * CZ_ERR_ARG ("reprime called with empty history"); n_targets == 0 -> 0.0.  smollm backend only. */
+ * CZ_ERR_ARG ("reprime called with empty history"); n_targets == 0 -> 0.0.
+ * rwkv7 backend = cross_entropy_bits_over_span_rwkv (src/main.rs:1753-1787): prime = history WITHOUT its literal symbols (id >= vocab) ++ hint,
+ * nothing cut (max_context_length() is usize::MAX there, src/models.rs:150); p = combined_pdf_with_literals(logits)[target], ac_p_min()
+ * for a target >= vocab + 256; the model steps on vocabulary targets only.  A hint token >= vocab is CZ_ERR_ARG (the reference's embedding
+ * lookup fails there). */
 cz_status cz_xe_bits_over_span(cz_session* s, const uint32_t* history, size_t n_history, const uint32_t* hint, size_t n_hint,
                                const uint32_t* targets, size_t n_targets, double* bits_out);
 cz_status cz_xe_bits_batch(cz_session* s, size_t n_spans, const uint32_t* const* history, const size_t* n_history,

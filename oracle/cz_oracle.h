@@ -148,6 +148,8 @@ size_t czo_rwkv7_encode_tokens(czo_rwkv7* s, const uint32_t* ids, size_t n, uint
                                uint8_t** payload, uint64_t* zero_width);
 int czo_rwkv7_decode_tokens(czo_rwkv7* s, const uint8_t* payload, size_t len, size_t token_count,
                             uint32_t bos, uint32_t* out_ids);
+int czo_rwkv7_xe_bits_over_span(czo_rwkv7* s, const uint32_t* history, size_t n_hist, const uint32_t* hint, size_t n_hint,
+                                const uint32_t* targets, size_t n_t, double* bits_out, double* p_out);   /* src/main.rs:1753-1787 */
 
 /* synthetic generator primitive (exposed for tests): bf16 bits of element idx of tensor tid */
 uint16_t czo_synth_bf16(uint64_t seed, uint32_t tid, uint64_t idx, float std, float mean);

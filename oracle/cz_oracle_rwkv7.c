@@ -315,3 +315,40 @@ int czo_rwkv7_decode_tokens(czo_rwkv7* s, const uint8_t* payload, size_t len, si
     free(logits); free(cdf);
     return 0;
 }
+
+/* cross_entropy_bits_over_span_rwkv (src/main.rs:1753-1787), statement by statement: max_ctx = max_context_length() - 1 with
+ * max_context_length() = usize::MAX for this session (src/models.rs:150), so nothing is ever cut; the history loses its literal symbols
+ * (:1764-1766), the hint is appended as it is (:1767-1772); empty prime -> error (:1773); reprime = state reset + the prime token by token
+ * (src/models.rs:161-178); per target: combined_pdf_with_literals, p = pdf[sym] or ac_p_min() past its end (:1777-1780),
+ * bits += -log2(max(p, 1e-300)), and the model steps on vocabulary symbols only (:1782-1784).
+ * Returns 0, -3 (empty prime), -4 (a prime token >= vocab: the reference's embedding lookup fails there).  p_out (optional): the n_t probabilities. */
+int czo_rwkv7_xe_bits_over_span(czo_rwkv7* s, const uint32_t* history, size_t n_hist, const uint32_t* hint, size_t n_hint,
+                                const uint32_t* targets, size_t n_t, double* bits_out, double* p_out) {
+    *bits_out = 0.0;
+    if (n_t == 0) return 0;                                              /* :1760 */
+    const size_t V = czo_rwkv7_vocab(s);
+    uint32_t* prime = (uint32_t*)malloc(sizeof(uint32_t) * (n_hist + n_hint + 1));
+    size_t np = 0;
+    for (size_t i = 0; i < n_hist; ++i) if (history[i] < V) prime[np++] = history[i];
+    for (size_t i = 0; i < n_hint; ++i) prime[np++] = hint[i];
+    if (np == 0) { free(prime); return -3; }
+    for (size_t i = 0; i < np; ++i) if (prime[i] >= V) { free(prime); return -4; }
+    float* logits = (float*)malloc(sizeof(float) * V);
+    double* pdf = (double*)malloc(sizeof(double) * (V + 256));
+    czo_rwkv7_reset(s);
+    int rc = 0;
+    for (size_t i = 0; i < np && rc == 0; ++i) rc = czo_rwkv7_step_logits(s, prime[i], logits);
+    double bits = 0.0;
+    for (size_t i = 0; i < n_t && rc == 0; ++i) {
+        czo_combined_pdf_with_literals(logits, V, pdf);
+        const size_t idx = targets[i];
+        double p = idx < V + 256 ? pdf[idx] : czo_ac_p_min();
+        if (p_out) p_out[i] = p;
+        if (!(p > 1e-300)) p = 1e-300;
+        bits += -log2(p);
+        if (idx < V) rc = czo_rwkv7_step_logits(s, targets[i], logits);
+    }
+    free(prime); free(logits); free(pdf);
+    *bits_out = bits;
+    return rc;
+}

@@ -407,6 +407,19 @@ class Rwkv7Session:
         assert rc == 0
         return out
 
+    def xe_bits_over_span(self, history, targets, hint=()):
+        """cross_entropy_bits_over_span_rwkv (src/main.rs:1753-1787): (bits, per-target probabilities); raises on an empty prime / a prime token >= vocab"""
+        h = np.ascontiguousarray(history, np.uint32); g = np.ascontiguousarray(hint, np.uint32); t = np.ascontiguousarray(targets, np.uint32)
+        bits = C.c_double(0.0); p = np.zeros(max(t.size, 1), np.float64)
+        f = lib().czo_rwkv7_xe_bits_over_span
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.c_void_p]
+        z = np.zeros(1, np.uint32)
+        rc = f(self.h, _p(h if h.size else z), h.size, _p(g if g.size else z), g.size, _p(t if t.size else z), t.size, C.byref(bits), _p(p))
+        if rc != 0:
+            raise ValueError(f"oracle rwkv7 xe_bits_over_span failed ({rc})")
+        return bits.value, p[: t.size]
+
 
 # ---------------------------------------------------------------- per-op references (kernel-level parity tests)
 def gemm_bf16(A, W_bf16, R=None):

@@ -333,6 +333,34 @@ def test_rwkv7_encode_decode_bitexact_with_literals(cz, czo, rwkv_pair):
         assert np.array_equal(out, s)
 
 
+def test_rwkv7_cross_entropy_bits_over_span_matches_oracle(cz, czo, rwkv_pair):
+    """cross_entropy_bits_over_span_rwkv (src/main.rs:1753-1787): the history loses its literal symbols, nothing is cut (max_context_length() is
+    usize::MAX), p = combined_pdf_with_literals(logits)[target] (three exact chains on the device), ac_p_min() for a target past vocab + 256, the
+    model steps on vocabulary targets only.  Same probabilities bit for bit, so (libm log2 and the running sum on the host on both sides) same bits."""
+    g, o = rwkv_pair
+    rng = np.random.default_rng(23)
+    V = 512
+    hist = rng.integers(0, V, 300).astype(np.uint32)
+    hist_lit = hist.copy(); hist_lit[[3, 50, 51, 299]] = [V + 7, V + 255, V + 0, V + 100]          # literals in the history: filtered out
+    t_mix = rng.integers(0, V, 40).astype(np.uint32); t_mix[[0, 5, 6, 39]] = [V + 1, V + 200, V + 255, V + 9]   # literal targets: scored, no step
+    t_far = rng.integers(0, V, 12).astype(np.uint32); t_far[[2, 11]] = [V + 256, V + 5000]           # past the pdf's end: ac_p_min(), no step
+    cases = [(hist, rng.integers(0, V, 64), ()), (hist_lit, t_mix, ()), (hist[:1], [7], ()), (hist, t_far, rng.integers(0, V, 20)),
+             ((), rng.integers(0, V, 9), rng.integers(0, V, 33)), (hist, (), ()), (hist_lit[:60], [V + 3, V + 4], [5]),
+             (hist, rng.integers(0, V, 700), ()), ([V + 1, 4, V + 2], [1, 2, 3], ())]
+    want = [o.xe_bits_over_span(h, t, hint)[0] for h, t, hint in cases]
+    got = g.xe_bits_batch([c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases])
+    assert got.tolist() == want
+    assert want[5] == 0.0 and g.xe_bits_over_span(hist_lit, t_mix) == want[1]
+    for h, t, hint, msg in (((), [1, 2, 3], (), "empty history"), ([V + 3, V + 9], [1], (), "empty history"), (hist, [1], [V], "hint token")):
+        with pytest.raises(cz.CandlezipError) as e:
+            g.xe_bits_over_span(h, t, hint)
+        assert msg in str(e.value)
+    assert g.debug_get("cdf_fallback_rows") == 0
+    # the stepping trait is still usable afterwards (the scorer resets the recurrent state, like the reference's reprime does)
+    o.reset()
+    _eq(g.reprime_with_history_and_get_last_logits_tensor(hist[:5]), [o.step_logits(t) for t in hist[:5]][-1], "rwkv reprime after xe")
+
+
 def test_rwkv7_lanes_match_single_group(cz, czo, rwkv_pair):
     """more streams than one lock-step group: RWKV encode AND decode run the groups concurrently on lanes (shared weights, own
     recurrent state); pairs, payloads and ids must equal the oracle's stream by stream, whatever the lane count"""
@@ -373,4 +401,7 @@ def test_rwkv7_0b1_shape_bitexact(cz, czo):
     lo, hi = g.encode_tokens(ids)
     assert np.array_equal(lo, clo) and np.array_equal(hi, chi)
     assert np.array_equal(g.decode_tokens(ref_p, 4), ids)
+    # the span scorer at this vocabulary (V + 256 = 65 792 symbols: 68 per thread in the literals-mode kernel), a literal and an out-of-range target among them
+    tg = np.array([toks[4], 65536 + 10, toks[5], 65536 + 256], np.uint32)
+    assert g.xe_bits_over_span(toks[:4], tg) == o.xe_bits_over_span(toks[:4], tg)[0]
     g.close(); o.close()
