@@ -16,6 +16,7 @@
 // a copy (the 1e-9 margin argument failed) the row falls back to the serial walk, so the result is exact regardless.
 //
 // Algorithmic traffic = vocab * 4 B of logits per row.  Bound: HBM for encode batches, latency for lock-step decode.
+#include <cstddef>
 #include "cz_cdf_common.h"
 
 #define T_PAR 1024
@@ -23,6 +24,7 @@
 #define LMAX_RWKV 68                   // 1024 x 68 >= 65 536 + 256 symbols (RWKV World vocabulary + literal bytes), multiple of 4
 #define NWAVE (T_PAR / 64)
 #define POOL_SLOTS 48
+#define CDF_STAGE_FLOATS 12288          // 48 KB at the start of par_smem_t double as the staging area of a row's logits (cdf_par_kernel's load phase)
 #define B_INVALID (-100000)
 #define B_EMPTY 100000
 
@@ -270,6 +272,7 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
                                                         unsigned long long step_i, unsigned* __restrict__ fallback_count,
                                                         const unsigned long long* __restrict__ step_dev) {
     __shared__ par_smem_t<LMAX> sm;
+    static_assert(offsetof(par_smem_t<LMAX>, pool_next) >= CDF_STAGE_FLOATS * sizeof(float), "the staging area must end before the fields that live across the load phase (flag, L, n, redf ...)");
     if (DECODE && step_dev) step_i = *step_dev;
     if (!DECODE && step_dev) { c_lo += *step_dev * (unsigned long long)rows; c_hi += *step_dev * (unsigned long long)rows; }   // lock-step encode under graph replay
     const int n = MODE ? V + 256 : V;                              // symbols of the coded alphabet
@@ -299,7 +302,49 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
         float m = -INFINITY;
         // Every load unconditional, from a clamped address (entries past the vocabulary are read but never used): a load inside a
         // per-lane `k < cnt` branch is waited for on the spot, i.e. up to LMAX dependent round trips per row.
-        if ((L & 3) == 0 && ((size_t)l & 15) == 0 && (V & 3) == 0 && V >= 4) {   // a lane's chunk is contiguous: 16-B loads (a quarter of the cache-line visits)
+        if (MODE == 1 && (L & 3) == 0 && ((size_t)l & 15) == 0 && (V & 3) == 0 && V >= 4) {
+            // (MODE 1 = the RWKV alphabets, 68 logits per thread: 8 192 rows 7.30 -> 5.38 ms, one decode row 198 -> 169 us.  The SmolLM alphabet,
+            // 48 per thread, LOSES with it — 2.32 -> 2.39 ms on the general instantiation, 2.89 on the FULL one — and keeps the direct loads below;
+            // profiles/r03_cdf_staged_load_kernel_times.txt.)
+            // A thread owns L CONSECUTIVE logits, so loading them straight from memory has the 64 lanes of a wave touch 64 different lines per
+            // instruction, and the block's 1024 x (L * 4 B) working set thrashes the 32 KB L1: a row's 192-256 KB took 27-56 us to arrive
+            // (profiles/r03_cdf_par_phases.txt).  Instead the block streams the row COALESCED (one KB per wave instruction) through the LDS that
+            // the chains use later — dead between rows —, a few waves' chunks per round, and every thread picks its chunk up from there.
+            // Chunks lie LP4 float4 apart with LP4 odd, so the sixteen lanes of a ds_read_b128 phase hit distinct banks.
+            const int L4 = L >> 2, LP4 = (L4 & 1) ? L4 : L4 + 1;
+            int RW = (CDF_STAGE_FLOATS / 4) / (64 * LP4);                     // waves whose chunks one round stages
+            RW = RW < 1 ? 1 : (RW > NWAVE ? NWAVE : RW);
+            const int per4 = RW * 64 * L4, V4 = V >> 2, rounds = (NWAVE + RW - 1) / RW;
+            float4* stage4 = reinterpret_cast<float4*>(&sm);
+            const float4* l4 = reinterpret_cast<const float4*>(l);
+            float4 pf[3];                                                      // (per4 <= CDF_STAGE_FLOATS / 4 = 3 x 1024)
+            auto issue = [&](const int r) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { int g = r * per4 + tid + T_PAR * i; g = g < V4 ? g : V4 - 1; pf[i] = l4[g]; }   // clamped, never conditional
+            };
+            issue(0);
+#pragma unroll 1
+            for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int f4 = tid + T_PAR * i;
+                    if (f4 < per4) {
+                        int dst = f4;
+                        if (LP4 != L4) { const int q = f4 / L4; dst = q * LP4 + (f4 - q * L4); }
+                        stage4[dst] = pf[i];
+                    }
+                }
+                if (r + 1 < rounds) issue(r + 1);                              // in flight across the two barriers below
+                __syncthreads();
+                if (wave / RW == r) {
+                    const float4* mine = stage4 + (tid - r * RW * 64) * LP4;
+#pragma unroll
+                    for (int k = 0; k < LMAX; k += 4)
+                        if (k < L) { const float4 q = mine[k >> 2]; ef[k] = q.x; ef[k + 1] = q.y; ef[k + 2] = q.z; ef[k + 3] = q.w; }
+                }
+                __syncthreads();
+            }
+        } else if ((L & 3) == 0 && ((size_t)l & 15) == 0 && (V & 3) == 0 && V >= 4) {   // a lane's chunk is contiguous: 16-B loads (a quarter of the cache-line visits)
 #pragma unroll
             for (int k = 0; k < LMAX; k += 4) {
                 const int at = FULL ? first + k : (first + k < V - 4 ? first + k : V - 4);
