@@ -29,6 +29,9 @@
     } while (0)
 #define CZCHK(expr) do { cz_status _s = (expr); if (_s != CZ_OK) return _s; } while (0)
 
+#ifndef RW_STATE_NT
+#define RW_STATE_NT 1          // rw_state_kernel streams its state tile with non-temporal loads / stores (tuning build: -DRW_STATE_NT=0)
+#endif
 int g_rw_state_pad = 0;        // tuning knob (cz_debug_set "rw_state_pad"): extra dynamic LDS bytes per rw_state_kernel block (fewer waves per CU -> several generations of waves, whose load / compute / store phases then overlap)
 __host__ __device__ __forceinline__ int kq_idx(int k) { return (k & ~63) | ((k & 3) << 4) | ((k & 63) >> 2); }
 
@@ -179,7 +182,8 @@ __global__ __launch_bounds__(64, 4) void rw_state_kernel(const float* __restrict
     float srow[64];
 #pragma unroll
     for (int j4 = 0; j4 < 16; ++j4) {
-        const float4 t4 = *reinterpret_cast<const float4*>(Srow + 256 * j4);
+        typedef float rw_f4 __attribute__((ext_vector_type(4)));
+        const rw_f4 t4 = RW_STATE_NT ? __builtin_nontemporal_load(reinterpret_cast<const rw_f4*>(Srow + 256 * j4)) : *reinterpret_cast<const rw_f4*>(Srow + 256 * j4);   // read once, written once per step: streamed past the caches
         srow[4 * j4] = t4.x; srow[4 * j4 + 1] = t4.y; srow[4 * j4 + 2] = t4.z; srow[4 * j4 + 3] = t4.w;
     }
     const float* p = P + (size_t)b * ldp;
@@ -228,7 +232,11 @@ __global__ __launch_bounds__(64, 4) void rw_state_kernel(const float* __restrict
         y = cz_fma(sn, bc[4][j], y);                                                        // (S' @ r)[i]
     }
 #pragma unroll
-    for (int j4 = 0; j4 < 16; ++j4) *reinterpret_cast<float4*>(Srow + 256 * j4) = make_float4(srow[4 * j4], srow[4 * j4 + 1], srow[4 * j4 + 2], srow[4 * j4 + 3]);
+    for (int j4 = 0; j4 < 16; ++j4) {
+        typedef float rw_f4 __attribute__((ext_vector_type(4)));
+        const rw_f4 o4 = rw_f4{srow[4 * j4], srow[4 * j4 + 1], srow[4 * j4 + 2], srow[4 * j4 + 3]};
+        if (RW_STATE_NT) __builtin_nontemporal_store(o4, reinterpret_cast<rw_f4*>(Srow + 256 * j4)); else *reinterpret_cast<rw_f4*>(Srow + 256 * j4) = o4;
+    }
     __syncthreads();
     tmp[i] = y;
     __syncthreads();
