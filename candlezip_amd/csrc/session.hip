@@ -988,7 +988,8 @@ static cz_status decode_llama_advance(cz_session* s, size_t n) {
     const int B = run.B; const size_t R = run.R, ec = run.ec;
     cz_dec_state* dst = (cz_dec_state*)s->decst.p;
     const size_t stop = run.max_tc - run.i < n ? run.max_tc : run.i + n;
-    if (run.use_graph && (s->graph_gen != s->devbuf_gen || s->graph_B != B || s->graph_max_nk != run.max_nk)) {
+    if (run.use_graph && run.i < stop && run.index_pos < s->ctx_cap && (s->graph_gen != s->devbuf_gen || s->graph_B != B || s->graph_max_nk != run.max_nk)) {
+        // (only when a step will run, and never with the position at the end of the cache: the dry run inside build_step_graph writes K/V at the live position)
         // another call on this session (an encode between two slices) grew a work buffer: the captured graph holds stale pointers.
         // The step's own buffers are re-sized by the dry run inside build_step_graph; the logits of the pending step live in step_logits
         // (never moved), so re-capturing here loses nothing.
