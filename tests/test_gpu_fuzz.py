@@ -64,10 +64,14 @@ def test_random_schedules_match_oracle(cz, czo):
 
 
 def test_random_rwkv_batches_match_oracle(cz, czo):
-    rng = np.random.default_rng(77)
+    """random batches through every RWKV7 form: token-by-token and sequence-parallel encode (time blocks of 7 / 64 / 32 768 rows), the narrow and the
+    wide (grouped-GEMM) decode step, lanes, literal symbols; and random spans through the span scorer.  CZ_FUZZ_RWKV_SEED / CZ_FUZZ_RWKV_CASES: soak runs."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("CZ_FUZZ_RWKV_SEED", "77")))
     o = czo.Rwkv7Session(czo.tiny_rwkv7_config(), seed=9, embed_std=0.05)
-    for case in range(8):
+    for case in range(int(os.environ.get("CZ_FUZZ_RWKV_CASES", "10"))):
         n_streams = int(rng.integers(1, 8)); max_streams = int(rng.choice([1, 2, 4])); lanes = int(rng.choice([1, 2, 3]))
+        seq = int(rng.choice([0, 1, 1])); seq_rows = int(rng.choice([7, 64, 32768])); wide = int(rng.choice([0, 1]))
         lens = [int(x) for x in rng.choice([0, 1, 2, 17, 64, 90, 150], n_streams)]
         lit = float(rng.choice([0.0, 0.05, 0.5]))                 # share of literal-byte symbols (they are coded but do not step the model)
         streams = []
@@ -78,16 +82,36 @@ def test_random_rwkv_batches_match_oracle(cz, czo):
             streams.append(np.concatenate([[0], body]).astype(np.uint32))
         g = cz.Session("rwkv7", cz.tiny_rwkv7_config(), seed=9, embed_std=0.05, max_streams=max_streams)
         g.debug_set("max_lanes", lanes)
+        g.debug_set("rwkv_seq", seq); g.debug_set("rwkv_seq_rows", seq_rows)
+        if wide:
+            g.debug_set("rwkv_wide_min", 1)                      # the wide (grouped-GEMM) decode step even for these few streams
         pairs = g.encode_tokens_batch(streams)
         pays = []
         for s, (lo, hi) in zip(streams, pairs):
             ref_p, clo, chi, zw = o.encode_tokens(s)
-            assert np.array_equal(lo, clo) and np.array_equal(hi, chi), (case, s.size)
+            assert np.array_equal(lo, clo) and np.array_equal(hi, chi), (case, s.size, seq, seq_rows)
             pays.append(cz.ac_encode_pairs(lo, hi)[0])
             assert pays[-1] == ref_p
         outs = g.decode_tokens_batch(pays, [s.size - 1 for s in streams])
         for s, out in zip(streams, outs):
-            assert np.array_equal(out, s), case
+            assert np.array_equal(out, s), (case, wide, lanes)
+        # the span scorer on pieces of the same streams: history with literals (filtered), a hint now and then, literal and out-of-range targets
+        spans = []
+        for s in streams:
+            if s.size < 4:
+                continue
+            cut = int(rng.integers(1, s.size - 1))
+            tg = s[cut: cut + int(rng.integers(1, 40))].copy()
+            if rng.random() < 0.3:
+                tg[int(rng.integers(0, tg.size))] = 512 + 256 + int(rng.integers(0, 1000))        # past vocab + 256: ac_p_min(), no step
+            hint = rng.integers(0, 512, int(rng.integers(0, 6))) if rng.random() < 0.5 else ()
+            if not (np.any(s[:cut] < 512) or len(hint)):
+                continue                                                                       # (an empty prime is the reference's error; covered in test_gpu_model.py)
+            spans.append((s[:cut], tg, hint))
+        if spans:
+            want = [o.xe_bits_over_span(h, t, hint)[0] for h, t, hint in spans]
+            got = g.xe_bits_batch([x[0] for x in spans], [x[1] for x in spans], [x[2] for x in spans])
+            assert got.tolist() == want, case
         assert g.debug_get("cdf_fallback_rows") == 0
         g.close()
     o.close()
