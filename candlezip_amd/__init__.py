@@ -148,6 +148,11 @@ def lib():
     return L
 
 
+def reset_process_knobs():
+    """every process-wide tuning knob back to the value the library ships with (cz_debug_set "reset_process_knobs"; needs no session)"""
+    _check(lib().cz_debug_set(None, b"reset_process_knobs", 0))
+
+
 def _check(rc):
     if rc != 0:
         raise CandlezipError(rc, (lib().cz_last_error() or b"").decode("utf-8", "replace"))

@@ -323,6 +323,10 @@ __global__ __launch_bounds__(T_PAR) void cdf_par_kernel(const float* __restrict_
                 for (int i = 0; i < 3; ++i) { int g = r * per4 + tid + T_PAR * i; g = g < V4 ? g : V4 - 1; pf[i] = l4[g]; }   // clamped, never conditional
             };
             issue(0);
+            // The staging area overlays fields of `sm` that the PREVIOUS row of this block reads until its very end (DECODE: sm.bexp[tid + 1] in the
+            // symbol search): no wave may write it before every wave has left that row.  Every path through the row loop ends in a barrier
+            // today; this one makes the overlay safe by construction (one barrier per row, under the first round's loads).
+            __syncthreads();
 #pragma unroll 1
             for (int r = 0; r < rounds; ++r) {
 #pragma unroll
@@ -680,20 +684,24 @@ hipError_t cz_launch_cdf_pairs(hipStream_t st, const float* logits, int ld, cons
                            0ull, fallback_count, out_step_dev);
     return hipGetLastError();
 }
+int g_cdf_dec_grid_cap = 0;   // test knob (cz_debug_set "cdf_dec_grid_cap"): at most this many blocks per decode launch, so that a block owns SEVERAL streams
+                              // (the row loop of the DECODE instantiations; 0 = one block per stream, what every real launch uses)
 hipError_t cz_launch_decode_symbol(hipStream_t st, const float* logits, int ld, cz_dec_state* st_arr, uint32_t* sym_out, int nstreams,
                                    int vocab, int mode, unsigned long long i, unsigned* fallback_count, const unsigned long long* step_dev,
                                    double* g_scratch) {
     if (nstreams <= 0) return hipSuccess;
     if (!cz_cdf_par_supported(vocab, mode)) return cz_launch_decode_symbol_serial(st, logits, ld, st_arr, sym_out, nstreams, vocab, mode, i, step_dev);
     if (!g_scratch || nstreams > CZ_CDF_PAR_MAX_GRID) return hipErrorInvalidValue;
+    const int rows_all = nstreams;                                            // (the kernels loop row = blockIdx.x, += gridDim.x over `rows`)
+    const int grid = g_cdf_dec_grid_cap > 0 && g_cdf_dec_grid_cap < nstreams ? g_cdf_dec_grid_cap : nstreams;
     if (mode == 0 && vocab == T_PAR * LMAX_SMOLLM)
-        hipLaunchKernelGGL((cdf_par_kernel<1, 0, LMAX_SMOLLM, true>), dim3(nstreams), dim3(T_PAR), 0, st, logits, ld, nstreams, vocab, nullptr, nullptr, nullptr, g_scratch,
+        hipLaunchKernelGGL((cdf_par_kernel<1, 0, LMAX_SMOLLM, true>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows_all, vocab, nullptr, nullptr, nullptr, g_scratch,
                            st_arr, sym_out, i, fallback_count, step_dev);
     else if (mode == 0)
-        hipLaunchKernelGGL((cdf_par_kernel<1, 0, LMAX_SMOLLM, false>), dim3(nstreams), dim3(T_PAR), 0, st, logits, ld, nstreams, vocab, nullptr, nullptr, nullptr, g_scratch,
+        hipLaunchKernelGGL((cdf_par_kernel<1, 0, LMAX_SMOLLM, false>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows_all, vocab, nullptr, nullptr, nullptr, g_scratch,
                            st_arr, sym_out, i, fallback_count, step_dev);
     else
-        hipLaunchKernelGGL((cdf_par_kernel<1, 1, LMAX_RWKV, false>), dim3(nstreams), dim3(T_PAR), 0, st, logits, ld, nstreams, vocab, nullptr, nullptr, nullptr, g_scratch,
+        hipLaunchKernelGGL((cdf_par_kernel<1, 1, LMAX_RWKV, false>), dim3(grid), dim3(T_PAR), 0, st, logits, ld, rows_all, vocab, nullptr, nullptr, nullptr, g_scratch,
                            st_arr, sym_out, i, fallback_count, step_dev);
     return hipGetLastError();
 }

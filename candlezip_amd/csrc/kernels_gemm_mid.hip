@@ -336,6 +336,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_mid_group_kernel(mid_group g,
     gemm_mid_body<1, 0, NW, PF, true>(pr.A, pr.lda, pr.Wk, pr.C, pr.ldc, nullptr, 0, M, pr.N, pr.K, local % nby, local / nby, mid_rope_args{});
 }
 
+int g_mid_cpw = -1;           // tuning knob (cz_debug_set "mid_cpw"): consecutive K chunks a wave owns per round (-1 = by K, see launch_mid)
 int g_mid_quad = 1;           // tuning knob (cz_debug_set "mid_quad"): 1 = the four-wave blocks share the ordered sum and the epilogue (QE), 0 = wave 0 does both
 int g_mid_colmaj = -1;        // tuning knob (cz_debug_set "mid_colmaj"): -1 = by operand sizes, 0 = row-major tile order, 1 = column-major
 template <int TN, int EPI, int NW, bool PF>

@@ -408,6 +408,14 @@ static cz_status ensure_streams(cz_session* s, int B, size_t need_ctx = 0, bool 
         cap = std::max(cap, (need_ctx + 255) / 256 * 256);
         cap = std::min(cap, (cz_ctx_limit(s) + 255) / 256 * 256);
         const size_t layer_stride = 2 * cap * kvd, stream_stride = (size_t)c.n_layers * layer_stride;
+        if (!fresh && !preserve) {
+            // nothing of the old cache is kept: give it back BEFORE asking for the longer one (512 streams x 30 layers x 2048 positions are 48 GB
+            // per lane; holding both would fail where the new size alone fits)
+            HIPCHK(hipStreamSynchronize(s->stream));
+            HIPCHK(hipFree(s->kvcache));
+            s->kvcache = nullptr; s->ctx_cap = 0;
+            ++s->devbuf_gen;                                                     // captured graphs hold kv offsets of the old capacity
+        }
         float* nk = nullptr;
         if (hipMalloc((void**)&nk, (size_t)s->max_streams * stream_stride * 4) != hipSuccess) {
             (void)hipGetLastError();
@@ -415,15 +423,13 @@ static cz_status ensure_streams(cz_session* s, int B, size_t need_ctx = 0, bool 
                          (double)s->max_streams * stream_stride * 4 / 1e9);
             return CZ_ERR_HIP;
         }
-        if (!fresh) {
+        if (!fresh && preserve) {                                                // a stepping stream keeps its keys: allocate, copy, free
             HIPCHK(hipStreamSynchronize(s->stream));
-            if (preserve) {
-                hipLaunchKernelGGL(kv_regrow_kernel, dim3(2048), dim3(256), 0, s->stream, s->kvcache, nk, (size_t)s->max_streams * c.n_layers, (int)kvd, s->ctx_cap, cap);
-                HIPCHK(hipGetLastError());
-                HIPCHK(hipStreamSynchronize(s->stream));
-            }
+            hipLaunchKernelGGL(kv_regrow_kernel, dim3(2048), dim3(256), 0, s->stream, s->kvcache, nk, (size_t)s->max_streams * c.n_layers, (int)kvd, s->ctx_cap, cap);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(s->stream));
             HIPCHK(hipFree(s->kvcache));
-            ++s->devbuf_gen;                                                     // captured graphs hold kv offsets of the old capacity
+            ++s->devbuf_gen;
         }
         s->kvcache = nk; s->ctx_cap = cap; s->kv_layer_stride = layer_stride; s->kv_stream_stride = stream_stride;
         std::vector<cz_seq_desc> sd(s->max_streams); std::vector<cz_rope_desc> rd(s->max_streams);
@@ -432,7 +438,8 @@ static cz_status ensure_streams(cz_session* s, int B, size_t need_ctx = 0, bool 
             sd[b] = {b, 1, 0, (int)kvd, kb, kb + s->ctx_cap * kvd, (int)s->ctx_cap, 0};     // K transposed [kvd][ctx_cap], V rows [ctx_cap][kvd]
             rd[b] = {b, 1, 0, (int)kvd, kb, kb + s->ctx_cap * kvd, (int)s->ctx_cap, 0};
         }
-        if (fresh) {
+        const bool first = !s->pos_dev;                                          // (a cache given back above and not replaced leaves these in place)
+        if (first) {
             HIPCHK(hipMalloc((void**)&s->pos_dev, 64));
             HIPCHK(hipMalloc((void**)&s->step_seqd, sd.size() * sizeof(cz_seq_desc)));
             HIPCHK(hipMalloc((void**)&s->step_roped, rd.size() * sizeof(cz_rope_desc)));
@@ -441,7 +448,7 @@ static cz_status ensure_streams(cz_session* s, int B, size_t need_ctx = 0, bool 
         HIPCHK(hipMemcpyAsync(s->step_seqd, sd.data(), sd.size() * sizeof(cz_seq_desc), hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipMemcpyAsync(s->step_roped, rd.data(), rd.size() * sizeof(cz_rope_desc), hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
-        if (fresh) {
+        if (first) {
             std::vector<int> ri(s->max_streams); for (int b = 0; b < s->max_streams; ++b) ri[b] = b;
             HIPCHK(hipMalloc((void**)&s->step_rows, ri.size() * 4));
             HIPCHK(hipMemcpyAsync(s->step_rows, ri.data(), ri.size() * 4, hipMemcpyHostToDevice, s->stream));
@@ -1037,10 +1044,11 @@ static cz_status decode_llama_advance(cz_session* s, size_t n) {
             }
             if (s->step_sync) HIPCHK(hipStreamSynchronize(s->stream));    // never more than one step of launches queued (profiler runs)
         }
-        // Bound what is queued behind the host: a token is 110-220 kernel packets, and thousands of them enqueued without a host
-        // synchronisation let the AQL ring back up when something serialises the dispatches — rocprofv3's counter collection does, and its
-        // write-interceptor then runs past the ring's end (SIGSEGV in librocprofiler-sdk, DESIGN.md §9: seen at ~8 k packets in flight, not
-        // at ~1.3 k).  One wait every CZ_SYNC_EVERY tokens costs one launch latency per 8 steps (< 0.3 % even for a single stream).
+        // Bound what is queued behind the host (a token is 110-220 kernel packets): a faulting kernel is reported within CZ_SYNC_EVERY tokens and
+        // the host never runs thousands of packets ahead of the device.  One wait every CZ_SYNC_EVERY tokens costs one launch latency per 8
+        // steps (< 0.3 % even for a single stream).  This is NOT a cure for the rocprofv3 SIGSEGV: that one is ROCr's intercept
+        // queue handing the profiler a packet batch that wraps the AQL ring's end — any multi-packet doorbell can do it (every hipGraphLaunch
+        // is one), a shallow queue only makes the batches of EAGER launches small.  Profile with tools/profile_pass.py (eager, step_sync).
         if (((i - run.i) % CZ_SYNC_EVERY) == CZ_SYNC_EVERY - 1) HIPCHK(hipStreamSynchronize(s->stream));
         index_pos += 1;
     }
@@ -1394,11 +1402,18 @@ extern "C" cz_status cz_profile_read(cz_session* s, cz_kernel_stat* out, size_t 
     *n = k;
     return CZ_OK;
 }
+// the streams THIS session's work runs on — its own, its decode lanes', its forks' (and their lanes') — and no other stream of the device:
+// another session, torch or RCCL work of the same process is not waited for
+static cz_status sync_session_tree(cz_session* s) {
+    if (s->stream) HIPCHK(hipStreamSynchronize(s->stream));
+    for (cz_session* l : s->lanes) if (l) CZCHK(sync_session_tree(l));
+    for (cz_session* f : s->forks) if (f) CZCHK(sync_session_tree(f));
+    return CZ_OK;
+}
 extern "C" cz_status cz_synchronize(cz_session* s) {
     if (!s) return CZ_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipDeviceSynchronize());                     // the session's stream, its decode lanes' and its forks'
-    return CZ_OK;
+    return sync_session_tree(s);
 }
 // tuning aid (tools/bench_decode_step.py): lock-step decode steps of B streams at a FIXED position `pos` (KV cache zeroed), as a replayed
 // hipGraph (use_graph) or eagerly (per-family HIP events when profiling is on).  iters <= 0 prepares (buffers, graph capture, one warm
@@ -1487,9 +1502,31 @@ static cz_status set_stream_priority(cz_session* s, int prio) {
     return CZ_OK;
 }
 
+// The process-wide knobs (the g_* globals of the kernel files) with the values they are shipped with, captured the first time any knob is
+// touched: "reset_process_knobs" puts every one of them back (the tests' fixture finalizer: a test that turned one leaves no trace for
+// the tests that run after it in the same process).
+extern int g_cdf_dec_grid_cap, g_gemm_lds_kb, g_attn_v1, g_dec_grid_target, g_dec_nw_cap, g_dec_mt_max, g_dec_norm_mfma, g_gemm_mid_rows, g_mid_nw, g_mid_colmaj, g_mid_quad, g_mid_cpw,
+           g_dec_attn_split_heads, g_dec_attn_lds_pad, g_dec_wide_rows, g_dec_attn_small_grid, g_dec_attn_split_max, g_rw_seq_rows, g_rw_state_pad;
+struct ProcKnob { const char* key; int* p; int shipped; };
+static std::vector<ProcKnob>& proc_knobs() {
+    static std::vector<ProcKnob> k;
+    if (k.empty()) {
+        const std::pair<const char*, int*> all[] = {
+            {"cdf_dec_grid_cap", &g_cdf_dec_grid_cap}, {"gemm_lds_kb", &g_gemm_lds_kb}, {"attn_v1", &g_attn_v1}, {"dec_grid_target", &g_dec_grid_target}, {"dec_nw_cap", &g_dec_nw_cap},
+            {"dec_mt_max", &g_dec_mt_max}, {"dec_norm_mfma", &g_dec_norm_mfma}, {"gemm_mid_rows", &g_gemm_mid_rows}, {"mid_nw", &g_mid_nw}, {"mid_colmaj", &g_mid_colmaj},
+            {"mid_quad", &g_mid_quad}, {"mid_cpw", &g_mid_cpw}, {"dec_attn_split_heads", &g_dec_attn_split_heads}, {"dec_attn_lds_pad", &g_dec_attn_lds_pad},
+            {"dec_wide_rows", &g_dec_wide_rows}, {"dec_attn_small_grid", &g_dec_attn_small_grid}, {"dec_attn_split_max", &g_dec_attn_split_max},
+            {"rwkv_seq_rows", &g_rw_seq_rows}, {"rw_state_pad", &g_rw_state_pad}};
+        for (const auto& a : all) k.push_back({a.first, a.second, *a.second});
+    }
+    return k;
+}
 // test/bench knobs (not part of the drop-in surface): 0 = default kernels
 extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
-    if (!s || !key) return CZ_ERR_ARG;
+    if (!key) return CZ_ERR_ARG;
+    std::vector<ProcKnob>& pk = proc_knobs();                // (before anything is changed: the shipped values)
+    if (!strcmp(key, "reset_process_knobs")) { for (auto& k : pk) *k.p = k.shipped; return CZ_OK; }   // (no session needed)
+    if (!s) return CZ_ERR_ARG;
     if (!strcmp(key, "force_big_gemm")) s->force_big_gemm = (int)value;
     else if (!strcmp(key, "max_batch_rows")) s->max_batch_rows = (size_t)value;
     else if (!strcmp(key, "logit_batch_rows")) s->logit_batch_rows = (size_t)value;
@@ -1515,6 +1552,8 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "mid_nw")) g_mid_nw = (int)value;
     else if (!strcmp(key, "mid_colmaj")) g_mid_colmaj = (int)value;
     else if (!strcmp(key, "mid_quad")) g_mid_quad = (int)value;
+    else if (!strcmp(key, "mid_cpw")) g_mid_cpw = (int)value;
+    else if (!strcmp(key, "cdf_dec_grid_cap")) g_cdf_dec_grid_cap = (int)value;
     else if (!strcmp(key, "dec_attn_split_heads")) g_dec_attn_split_heads = (int)value;
     else if (!strcmp(key, "dec_attn_lds_pad")) g_dec_attn_lds_pad = (int)value;              // (before the first decode: the kernels' LDS limit is set once)
     else if (!strcmp(key, "dec_wide_rows")) g_dec_wide_rows = (int)value;
@@ -1534,6 +1573,7 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
 // number of rows the exact-parallel CDF kernel handed to the serial walk since the session was opened
 extern "C" long cz_debug_get(cz_session* s, const char* key) {
     if (!s || !key) return -1;
+    for (const ProcKnob& k : proc_knobs()) if (!strcmp(key, k.key)) return (long)*k.p;      // a process-wide knob's current value
     if (!strcmp(key, "graph_launch_cpu_us")) { unsigned long long t = s->graph_launch_cpu_ns; s->graph_launch_cpu_ns = 0; return (long)(t / 1000); }
     if (!strcmp(key, "graph_launch_idle_us")) { unsigned long long t = s->graph_launch_idle_ns; s->graph_launch_idle_ns = 0; return (long)(t / 1000); }   // first 64 launches
     if (!strcmp(key, "graph_launch_us")) { unsigned long long t = s->graph_launch_ns; s->graph_launch_ns = 0; return (long)(t / 1000); }   // host time inside hipGraphLaunch

@@ -219,7 +219,9 @@ typedef struct cz_kernel_stat {
 } cz_kernel_stat;
 cz_status cz_profile_enable(cz_session* s, int on);                       /* resets the accumulators */
 cz_status cz_profile_read(cz_session* s, cz_kernel_stat* out, size_t cap, size_t* n);
-/* synchronise the session's device: its own stream, its decode lanes' and its forks' (bench brackets the timed region with it) */
+/* wait for the work of THIS session: its own HIP stream, its decode lanes' and its forks' (and their lanes'), each with
+ * hipStreamSynchronize — other sessions, torch or RCCL work on the same device are not waited for (bench brackets the timed
+ * region with it) */
 cz_status cz_synchronize(cz_session* s);
 
 #ifdef __cplusplus

@@ -22,3 +22,13 @@ def czo():
 @pytest.fixture(scope="session")
 def golden():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _shipped_process_knobs(request):
+    """Process-wide tuning knobs (cz_debug_set keys backed by globals of the kernel files: mid_nw, dec_attn_split_max, ...) go back to the
+    values the library ships with after EVERY GPU test, so that no test sees another test's configuration (the suite runs in one process)."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import candlezip_amd
+        candlezip_amd.reset_process_knobs()

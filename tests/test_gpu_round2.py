@@ -193,12 +193,12 @@ def test_wide_group_step_is_bitexact(cz, czo, shape, path):
         g.debug_set("no_last_prune", 1)                                   # ... and the last layer runs its tail on every row (the other paths: wanted rows only)
     elif path.startswith("mid"):                                          # the K-group GEMM (kernels_gemm_mid.hip) for the four layer projections
         g.debug_set("wide_min_streams", 1); g.debug_set("wide_mode", 3)
-        g.debug_set("mid_nw", {"mid": 4, "mid_q0": 4, "mid8": 8, "mid9": 0}[path])     # (process-wide knob: reset below)
+        g.debug_set("mid_nw", {"mid": 4, "mid_q0": 4, "mid8": 8, "mid9": 0}[path])     # (process-wide knob: reset by conftest)
         g.debug_set("mid_quad", 0 if path == "mid_q0" else 1)             # four-wave blocks: wave 0 alone sums and runs the epilogue (0) / all four waves share both (1, the default)
     elif path == "hybrid":                                                # tiled QKV / lm_head, dec_gemm 32 x 64 blocks for the other projections
         g.debug_set("wide_min_streams", 1); g.debug_set("wide_mode", 2); g.debug_set("dec_wide_rows", 1)
     else:
-        g.debug_set("wide_min_streams", 0); g.debug_set("dec_wide_rows", 1)   # ... or the wide dec_gemm blocks (process-wide knob: reset below)
+        g.debug_set("wide_min_streams", 0); g.debug_set("dec_wide_rows", 1)   # ... or the wide dec_gemm blocks (process-wide knob: reset by conftest)
     rng = np.random.default_rng(21)
     toks = rng.integers(0, V, 30).astype(np.uint32)
     _eq(g.reprime_with_history_and_get_last_logits_tensor(toks[:1]), o.reprime_logits(toks[:1]), "bos")
@@ -221,7 +221,7 @@ def test_wide_group_step_is_bitexact(cz, czo, shape, path):
         for s_, out, (_, z) in zip(streams, outs, coded):
             if z == 0:
                 assert np.array_equal(out, s_)
-    g.debug_set("dec_wide_rows", 256); g.debug_set("dec_attn_small_grid", 128); g.debug_set("mid_nw", 4); g.debug_set("dec_attn_split_heads", 1); g.debug_set("dec_attn_split_max", 128); g.debug_set("mid_quad", 1)
+    # (the process-wide knobs touched above go back to their shipped values in conftest's fixture finalizer)
     g.close(); o.close()
 
 

@@ -291,5 +291,4 @@ def test_split_decode_attention_of_small_groups_is_bitexact(cz, czo, shape):
             assert np.array_equal(x, y)
             if z == 0:
                 assert np.array_equal(x, s_)
-    g.debug_set("dec_attn_split_max", 128); g.debug_set("no_graph", 0)
-    g.close(); o.close()
+    g.close(); o.close()                                                         # (dec_attn_split_max: reset by conftest's fixture finalizer)

@@ -1,0 +1,95 @@
+"""Round-4 GPU parity tests: decode-CDF blocks that own several streams (the row loop of the DECODE instantiations of cdf_par_kernel, which
+real launches never take: one block per stream), the shipped values of the process-wide knobs, the K-group GEMM with consecutive K chunks
+per wave, and a KV cache that is replaced (not grown) between two runs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cz():
+    import candlezip_amd as m
+    m.lib()
+    return m
+
+
+@pytest.mark.parametrize("backend,shape", [("rwkv7", "0b1"), ("rwkv7", "tiny"), ("smollm", "tiny"), ("smollm", "135m")])
+def test_decode_blocks_that_own_several_streams(cz, czo, backend, shape):
+    """cdf_dec_grid_cap = 2: five streams on two blocks, so a block walks rows 0, 2, 4 / 1, 3 of ONE launch — the staged row load of the
+    literals mode (RWKV7-0.1B alphabet: 68 logits per thread) overlays LDS fields the previous row reads until its end; finished and empty
+    streams take the early `continue`.  Against the oracle's payloads, graph replay and eager."""
+    if backend == "rwkv7":
+        if shape == "tiny":
+            gcfg, ocfg, V, n_tok, seed, std = cz.tiny_rwkv7_config(), czo.tiny_rwkv7_config(), 512, 90, 9, 0.05
+        else:
+            gcfg, ocfg, V, n_tok, seed, std = cz.rwkv7_0b1_config(), czo.rwkv7_0b1_config(), 65536, 9, 3, 0.02
+        o = czo.Rwkv7Session(ocfg, seed=seed, embed_std=std)
+    else:
+        if shape == "tiny":
+            gcfg, ocfg, V, n_tok, seed, std = cz.tiny_llama_config(), czo.tiny_llama_config(), 512, 90, 11, 0.05
+        else:
+            gcfg, ocfg, V, n_tok, seed, std = cz.smollm2_135m_config(), czo.smollm2_135m_config(), 49152, 9, 0x5EED, 0.02
+        o = czo.SmolLmSession(ocfg, seed=seed, embed_std=std)
+    g = cz.Session(backend, gcfg, seed=seed, embed_std=std, max_streams=5)
+    rng = np.random.default_rng(41)
+    lens = [n_tok, n_tok // 2, 1, 0, n_tok - 2]
+    streams = [np.concatenate([[0], rng.integers(0, V, n)]).astype(np.uint32) for n in lens]
+    if backend == "rwkv7":
+        streams[0][2] = V + 65; streams[4][3] = V + 200                     # literal symbols: coded, never stepped
+    pays = []
+    for s_, (lo, hi) in zip(streams, g.encode_tokens_batch(streams)):
+        ref_p, clo, chi, zw = o.encode_tokens(s_)
+        assert np.array_equal(lo, clo) and np.array_equal(hi, chi)
+        pays.append((ref_p, zw))
+    for cap in (2, 0):
+        g.debug_set("cdf_dec_grid_cap", cap)
+        for no_graph in (0, 1):
+            g.debug_set("no_graph", no_graph)
+            outs = g.decode_tokens_batch([p for p, _ in pays], lens)
+            for s_, out, (_, zw) in zip(streams, outs, pays):
+                if zw == 0:
+                    assert np.array_equal(out, s_), (cap, no_graph)
+    assert g.debug_get("cdf_fallback_rows") == 0
+    g.close(); o.close()
+
+
+def test_process_knobs_go_back_to_their_shipped_values(cz):
+    """every process-wide knob is restored by cz_debug_set("reset_process_knobs") (conftest's finalizer after each GPU test): a session that
+    turned them decodes like a fresh process afterwards"""
+    g = cz.Session("smollm", cz.tiny_llama_config(), seed=11, embed_std=0.05, max_streams=4)
+    rng = np.random.default_rng(5)
+    ids = np.concatenate([[0], rng.integers(0, 512, 200)]).astype(np.uint32)
+    lo, hi = g.encode_tokens(ids)
+    pay, zw = cz.ac_encode_pairs(lo, hi)
+    shipped = {k: g.debug_get(k) for k in ("dec_attn_split_max", "mid_nw", "mid_quad", "dec_wide_rows", "cdf_dec_grid_cap")}
+    assert shipped["dec_attn_split_max"] == 36 and shipped["mid_nw"] == 4 and shipped["cdf_dec_grid_cap"] == 0
+    for k in shipped:
+        g.debug_set(k, 1)
+    assert all(g.debug_get(k) == 1 for k in shipped)
+    cz.reset_process_knobs()
+    assert {k: g.debug_get(k) for k in shipped} == shipped
+    if zw == 0:
+        assert np.array_equal(g.decode_tokens(pay, 200), ids)
+    g.close()
+
+
+def test_kv_cache_replaced_between_runs_keeps_results(cz, czo):
+    """a run whose schedule needs a longer KV cache than the previous run left behind: nothing of the old cache is kept, so it is given back
+    BEFORE the longer one is allocated (ensure_streams); the new run and a later short run decode exactly"""
+    g = cz.Session("smollm", cz.tiny_llama_config(), seed=11, embed_std=0.05, max_streams=2)
+    o = czo.SmolLmSession(czo.tiny_llama_config(), seed=11, embed_std=0.05)
+    g.debug_set("kv_ctx_cap", 256)                                           # a deliberately short first cache
+    rng = np.random.default_rng(2)
+    short = [np.concatenate([[0], rng.integers(0, 512, n)]).astype(np.uint32) for n in (120, 60)]
+    long_ = [np.concatenate([[0], rng.integers(0, 512, n)]).astype(np.uint32) for n in (700, 300)]
+    for streams, (ctx, R) in ((short, (512, 512)), (long_, (512, 2048)), (short, (512, 512))):     # 121 keys; 701 keys in one sawtooth tooth; 121 again
+        pairs = g.encode_tokens_batch(streams, ctx, R)
+        pays = [cz.ac_encode_pairs(lo, hi) for lo, hi in pairs]
+        ref_p, clo, chi, zw = o.encode_tokens(streams[0], ctx, R)
+        assert pays[0][0] == ref_p
+        outs = g.decode_tokens_batch([p for p, _ in pays], [len(s_) - 1 for s_ in streams], ctx, R)
+        for s_, out, (_, z) in zip(streams, outs, pays):
+            if z == 0:
+                assert np.array_equal(out, s_)
+    g.close(); o.close()
