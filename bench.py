@@ -581,7 +581,7 @@ def main():
         shutil.copy("/proc/self/maps", os.environ["CZ_DUMP_MAPS"])
 
     def barrier():
-        sess.synchronize()                                       # hipDeviceSynchronize: every lane and fork of this rank
+        sess.synchronize()                                       # every stream of this rank's session: its lanes' and its forks' (the encoder)
         if dist is not None:
             dist.barrier()
             sess.synchronize()
@@ -589,6 +589,9 @@ def main():
     sess.profile_enable(False)
     pipe.fill()                                                           # untimed: the compress stage two windows ahead, the decode opened
     note("pipeline filled (compress stage two windows ahead)")
+    if os.environ.get("CZ_DUMP_MAPS"):      # ... and again with every lane's HIP stream (its AQL ring) in existence
+        import shutil
+        shutil.copy("/proc/self/maps", os.environ["CZ_DUMP_MAPS"] + ".filled")
     for _ in range(args.warmup):                                          # W untimed steps of the same pipeline (first one builds the decode hipGraphs)
         pipe.step()
     pipe.te = pipe.td = 0.0; pipe.tok = 0
