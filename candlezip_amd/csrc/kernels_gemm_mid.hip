@@ -319,186 +319,6 @@ __global__ __launch_bounds__(NW * 64, (TN == 1 && NW == 9) ? 5 : ((TN == 2 && NW
     gemm_mid_body<TN, EPI, NW, PF, QE>(A, lda, Wk, C, ldc, R, ldr, M, N, K, bm, bn, ra_);
 }
 
-// ---- Round 4: CONSECUTIVE K chunks per wave.  The rounds above cost a block one memory round trip each (the next tile is requested one round ahead and
-// waited for under a 0.85 us chain: profiles/r03_mid_phases_b512.json reads 2.0 us of "staging + MFMA chain" per round), two barriers and an ordered
-// hand-over; K = 576 is three rounds of 4 + 4 + 1 tiles with three waves idle in the last.  Here wave g of the four owns CPW consecutive chunks per round
-// — round rd = chunks [rd 4 CPW, (rd + 1) 4 CPW), wave g takes (4 rd + g) CPW + c, c < CPW — and requests ALL of them (and the epilogue's operands:
-// residual, rotation table, cache descriptors) before it touches the first: K = 576 (nine chunks) and RWKV7's K = 768 (twelve) are ONE round with ONE
-// memory round trip, K = 1536 two rounds whose second is in flight under the first.  Same chunk partials, same left-to-right order of their sum (wave w
-// adds ITS register quad of every parked tile, chunk by chunk): the bits do not change.  A wave's partials of chunks c < CPW - 1 go to LDS of their own,
-// the last one on top of its spent activation tile: 8.7 KB + (CPW - 1) 4 KB per wave, 67.6 KB per block at CPW = 3 — two blocks per CU, which is what
-// 288-480 blocks on 256 CUs need.  TN = 1 only (gate|up keeps the form above: it is bound by the MFMA rate inside its blocks, three per CU).
-#define MID_CPW 3     // consecutive chunks per wave and round of gemm_mid_c_kernel (launch_mid)
-template <int CPW> struct mid_c_lds { static constexpr int WAVE_FLOATS = 32 * MID_LDK + (CPW - 1) * 1024; };
-template <int EPI, int CPW, int RMAX>
-__device__ __forceinline__ void gemm_mid_body_c(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Wk,
-                                                float* __restrict__ C, int ldc, const float* __restrict__ R, int ldr,
-                                                int M, int N, int K, const int bm, const int bn, const mid_rope_args& ra_) {
-    constexpr int NW = 4, WF = mid_c_lds<CPW>::WAVE_FLOATS;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* As = smem + wave * WF;                                        // wave-private activation tile [32][MID_LDK]; behind it CPW - 1 parked partial tiles
-    const int lr = lane & 31, lh = lane >> 5;
-    const int nk = K >> 6, per_round = NW * CPW;                         // (RMAX = ceil(nk / per_round) rounds)
-    const int srow = lane >> 3, sg = lane & 7;
-
-    f32x4 ra[CPW][4][2];
-    uint4 rb[CPW][4];
-    auto load_tile = [&](const int c, const int kt) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int row = min(bm * 32 + p * 8 + srow, M - 1);          // (no branch around a load: see gemm_mid_body)
-            const f32x4* src = reinterpret_cast<const f32x4*>(A + (size_t)row * lda + kt * 64 + sg * 8);
-            ra[c][p][0] = src[0]; ra[c][p][1] = src[1];
-        }
-        const uint4* src = reinterpret_cast<const uint4*>(Wk + (size_t)(bn * 32 + lr) * K + kt * 64 + lh * 32);
-        rb[c][0] = src[0]; rb[c][1] = src[1]; rb[c][2] = src[2]; rb[c][3] = src[3];
-    };
-    auto slot = [&](float* base, const int c) -> float* { return c == CPW - 1 ? base : base + 32 * MID_LDK + c * 1024; };   // where chunk c of a wave is parked
-
-    MST_BEGIN;
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) { const int kt = wave * CPW + c; if (kt < nk) load_tile(c, kt); }
-    // the epilogue's operands, requested behind the tiles: they arrive under the chains instead of costing a round trip (two for the rotation: the
-    // position, then the table row) after the last barrier.  This wave's quad = rows bm 32 + 8 wave + 4 lh + e, e < 4, column bn 32 + lr.
-    const int erow0 = bm * 32 + 8 * wave + 4 * lh;
-    float rv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    int pos = 0; float rc = 0.0f, rs = 0.0f; cz_rope_desc rd4[4];
-    if (EPI == 0 && R) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rv[e] = R[(size_t)min(erow0 + e, M - 1) * ldr + bn * 32 + lr];
-    }
-    if (EPI == 2) {
-        pos = ra_.pos_dev ? *ra_.pos_dev : ra_.descs[0].pos0;
-        const int t = (bn & 1) * 16 + (lr & 15);
-        rc = ra_.cs[(size_t)pos * 32 + t]; rs = ra_.sn[(size_t)pos * 32 + t];
-        if ((bn >> 1) >= ra_.n_heads) {                                  // (block-uniform) a K or V block: its rows' cache descriptors
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rd4[e] = ra_.descs[min(erow0 + e, M - 1)];
-        }
-    }
-    MST(1);
-    f32x4 tot = {0.0f, 0.0f, 0.0f, 0.0f};
-    // The rounds are unrolled (RMAX of them at most): a runtime loop would carry the tile registers around its back edge, and hipcc then copies the next
-    // round's tiles into them — behind an s_waitcnt vmcnt(0) that it schedules INTO the running MFMA chain (a memory round trip per chunk).
-#pragma unroll
-    for (int rd = 0; rd < RMAX; ++rd) {                                  // (RMAX == rounds: launch_mid_c)
-#pragma unroll
-        for (int c = 0; c < CPW; ++c) {
-            const int kt = (rd * NW + wave) * CPW + c;
-            if (kt < nk) {                                               // (wave-uniform)
-                // LDS image as in gemm_mid_body: within every group of 8 k the even k first, then the odd k
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    float* dst = As + (p * 8 + srow) * MID_LDK + sg * 8;
-                    *reinterpret_cast<f32x4*>(dst) = f32x4{ra[c][p][0][0], ra[c][p][0][2], ra[c][p][1][0], ra[c][p][1][2]};
-                    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{ra[c][p][0][1], ra[c][p][0][3], ra[c][p][1][1], ra[c][p][1][3]};
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): this wave's LDS writes are visible to its own lanes
-                unsigned wb[16];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { wb[4 * q] = rb[c][q].x; wb[4 * q + 1] = rb[c][q].y; wb[4 * q + 2] = rb[c][q].z; wb[4 * q + 3] = rb[c][q].w; }
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    const f32x4 af = *reinterpret_cast<const f32x4*>(As + lr * MID_LDK + g * 8 + lh * 4);
-#pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_) {
-                        const int t = 4 * g + s_;                         // MFMA step: k = 2t + lh
-                        const unsigned w = wb[t >> 1];
-                        const float bv = (t & 1) ? cz_bits_f32(w & 0xffff0000u) : cz_bits_f32(w << 16);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s_], bv, acc, 0, 0, 0);
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_s_waitcnt(0xc07f);                    // (the reads of As are done before the next tile, or the last partial, goes on top of it)
-                float* ps = slot(As, c);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<f32x4*>(ps + (q * 64 + lane) * 4) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-            }
-            // The next round's tile of this slot: requested once the slot's registers are spent, CPW - 1 chains and a barrier before it is used.
-            // OUTSIDE every runtime condition (RMAX == rounds; a chunk past the end re-reads the last one and is never used): a load that merges
-            // with a path on which the registers keep their old value lands in registers of its own and is COPIED into the tile's — behind a wait
-            // that hipcc schedules into the running MFMA chain (a memory round trip per chunk; seen in the ISA of the first two versions).
-            if (rd + 1 < RMAX) load_tile(c, min(kt + per_round, nk - 1));
-        }
-        MST(3);
-        __syncthreads();                                                // the partials of round rd are complete
-        MST(4);
-#pragma unroll
-        for (int v = 0; v < NW; ++v)
-#pragma unroll
-            for (int c = 0; c < CPW; ++c)
-                if ((rd * NW + v) * CPW + c < nk) {
-                    const f32x4 q = *reinterpret_cast<const f32x4*>(slot(smem + v * WF, c) + (wave * 64 + lane) * 4);
-                    if (rd == 0 && v == 0 && c == 0) tot = q;
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) tot[e] = tot[e] + q[e];
-                    }
-                }
-        MST(5);
-        if (rd + 1 < RMAX) __syncthreads();                              // the parked tiles are free for the next round's activations
-    }
-    // this wave holds registers 4 wave .. 4 wave + 3 of the 32 x 32 tile: rows erow0 + e, column bn 32 + lr
-    if (EPI == 2) {
-        const int nrot = (ra_.n_heads + ra_.n_kv) * 64, col0 = bn * 32;
-        if (col0 < nrot) {
-            const int h = bn >> 1, t = (bn & 1) * 16 + (lr & 15);
-            const bool lo = lr < 16;                                     // lanes lr and lr ^ 16 hold the pair (t, t + 32) of head h
-            const int dim = t + (lo ? 0 : 32);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = erow0 + e;
-                const float mine = tot[e], other = __shfl_xor(mine, 16);
-                const float x1 = lo ? mine : other, x2 = lo ? other : mine;
-                const float pa = x1 * (lo ? rc : rs), pb = x2 * (lo ? rs : rc);      // lo: x1 c, x2 s; hi: x1 s, x2 c
-                const float o = lo ? pa - pb : pa + pb;
-                if (row < M) {
-                    if (h < ra_.n_heads) C[(size_t)row * ldc + h * 64 + dim] = o;
-                    else {
-                        const cz_rope_desc& d = rd4[e];
-                        const int kd = (h - ra_.n_heads) * 64 + dim;
-                        if (d.kt_stride) d.k_dst[ra_.kv_off + (size_t)kd * d.kt_stride + pos] = o;
-                        else d.k_dst[ra_.kv_off + (size_t)pos * d.dst_stride + kd] = o;
-                    }
-                }
-            }
-        } else {
-            const int vc = col0 - nrot + lr;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = erow0 + e;
-                if (row < M) rd4[e].v_dst[ra_.kv_off + (size_t)pos * rd4[e].dst_stride + vc] = tot[e];
-            }
-        }
-        MST(15);
-        return;
-    }
-    const int col = bn * 32 + lr;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int row = erow0 + e;
-        float v = (EPI == 0 && R) ? tot[e] + rv[e] : tot[e];
-        if (EPI == 3) { const float z = tot[e] > 0.0f ? tot[e] : 0.0f; v = z * z; }
-        if (row < M) C[(size_t)row * ldc + col] = v;
-    }
-    MST(15);
-}
-template <int EPI, int CPW, int RMAX>
-__global__ __launch_bounds__(256, 2) void gemm_mid_c_kernel(const float* __restrict__ A, int lda, const uint16_t* __restrict__ Wk,
-                                                            float* __restrict__ C, int ldc, const float* __restrict__ R, int ldr,
-                                                            int M, int N, int K, int nbx, int nblocks, int colmaj, mid_rope_args ra_) {
-    const int sid = mid_xcd_remap(blockIdx.x, nblocks);
-    const int nby = nblocks / nbx;
-    const int bm = colmaj ? sid % nby : sid / nbx, bn = colmaj ? sid / nby : sid % nbx;
-    gemm_mid_body_c<EPI, CPW, RMAX>(A, lda, Wk, C, ldc, R, ldr, M, N, K, bm, bn, ra_);
-}
-
 // Several independent plain GEMMs that share M in ONE launch (the RWKV7 time-mix: seven projections of differently mixed inputs, then four
 // LoRA up-projections): tile t of the launch belongs to the problem z with tile0[z] <= t < tile0[z + 1]; column-major inside a problem (a
 // few hundred rows against 768-wide weight panels: the weights are the larger operand).
@@ -516,18 +336,6 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_mid_group_kernel(mid_group g,
     gemm_mid_body<1, 0, NW, PF, true>(pr.A, pr.lda, pr.Wk, pr.C, pr.ldc, nullptr, 0, M, pr.N, pr.K, local % nby, local / nby, mid_rope_args{});
 }
 
-template <int CPW>
-__global__ __launch_bounds__(256, 2) void gemm_mid_group_c_kernel(mid_group g, int M, int nblocks) {
-    const int sid = mid_xcd_remap(blockIdx.x, nblocks);
-    int z = 0;
-#pragma unroll
-    for (int q = 1; q < MID_GROUP_MAX; ++q) if (q < g.n && sid >= g.tile0[q]) z = q;
-    const mid_prob pr = g.p[z];
-    const int local = sid - g.tile0[z], nby = (M + 31) / 32;
-    gemm_mid_body_c<0, CPW, 1>(pr.A, pr.lda, pr.Wk, pr.C, pr.ldc, nullptr, 0, M, pr.N, pr.K, local % nby, local / nby, mid_rope_args{});     // (K <= 4 CPW chunks: one round)
-}
-
-int g_mid_cpw = -1;           // tuning knob (cz_debug_set "mid_cpw"): 0 = never the consecutive-chunk form (gemm_mid_c_kernel), 1 = for every K that fits (tests), -1 = from nine chunks on
 int g_mid_quad = 1;           // tuning knob (cz_debug_set "mid_quad"): 1 = the four-wave blocks share the ordered sum and the epilogue (QE), 0 = wave 0 does both
 int g_mid_colmaj = -1;        // tuning knob (cz_debug_set "mid_colmaj"): -1 = by operand sizes, 0 = row-major tile order, 1 = column-major
 template <int TN, int EPI, int NW, bool PF>
@@ -565,11 +373,6 @@ hipError_t cz_gemm_mid_prepare() {
     if (e == hipSuccess) e = mid_prepare_epi<1, 3>();
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_mid_group_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)((size_t)(4 * 32 * MID_LDK + 4) * sizeof(float)));
-    auto prep_c = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)4 * mid_c_lds<MID_CPW>::WAVE_FLOATS * sizeof(float))); };
-    prep_c(reinterpret_cast<const void*>(gemm_mid_c_kernel<0, MID_CPW, 1>)); prep_c(reinterpret_cast<const void*>(gemm_mid_c_kernel<0, MID_CPW, 2>)); prep_c(reinterpret_cast<const void*>(gemm_mid_c_kernel<0, MID_CPW, 3>)); prep_c(reinterpret_cast<const void*>(gemm_mid_c_kernel<0, MID_CPW, 4>));
-    prep_c(reinterpret_cast<const void*>(gemm_mid_c_kernel<2, MID_CPW, 1>)); prep_c(reinterpret_cast<const void*>(gemm_mid_c_kernel<2, MID_CPW, 2>)); prep_c(reinterpret_cast<const void*>(gemm_mid_c_kernel<2, MID_CPW, 3>)); prep_c(reinterpret_cast<const void*>(gemm_mid_c_kernel<2, MID_CPW, 4>));
-    prep_c(reinterpret_cast<const void*>(gemm_mid_c_kernel<3, MID_CPW, 1>)); prep_c(reinterpret_cast<const void*>(gemm_mid_c_kernel<3, MID_CPW, 2>)); prep_c(reinterpret_cast<const void*>(gemm_mid_c_kernel<3, MID_CPW, 3>)); prep_c(reinterpret_cast<const void*>(gemm_mid_c_kernel<3, MID_CPW, 4>));
-    prep_c(reinterpret_cast<const void*>(gemm_mid_group_c_kernel<MID_CPW>));
     return e;
 }
 // K groups per block.  Round 3, with the ordered sum and the epilogue shared by four waves (QE), 512 rows, ms per decode step
@@ -579,33 +382,9 @@ hipError_t cz_gemm_mid_prepare() {
 // the fewest K tiles: +2 %, call26) — a block's latency is dominated by its first, cold operand load and by
 // the 0.85 us dependent MFMA chain per chunk, and four-wave blocks pack four to a CU where nine-wave blocks pack one or two.
 int g_mid_nw = 4;             // tuning knob (cz_debug_set "mid_nw"): 4 / 8 = that many K groups with operand prefetch, 0 = nine (K <= 576, one round) or twelve
-// consecutive chunks per wave for a K of nk chunks: 0 = the round-robin form above.  By default three per wave from nine chunks on (K = 576: one round of
-// 3 + 3 + 3; K = 768: one of 4 x 3; K = 1536: two; K = 3072: four); shorter K (the LoRA up-projections of RWKV7) keeps the round-robin form, whose blocks
-// are a third the LDS, and so does a K of more than four rounds.
-static int mid_cpw_for(int nk) {
-    if (g_mid_nw != 4 || !g_mid_quad || g_mid_cpw == 0) return 0;
-    return nk >= (g_mid_cpw > 0 ? 1 : 9) && nk <= 4 * 4 * MID_CPW ? MID_CPW : 0;       // (mid_cpw = 1: every K that fits, the tests' short ones too)
-}
-template <int EPI, int RMAX>
-static hipError_t launch_mid_c(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* C, int ldc, const float* R, int ldr, int M, int N, int K, mid_rope_args ra) {
-    const size_t smem = (size_t)(4 * mid_c_lds<MID_CPW>::WAVE_FLOATS) * sizeof(float);
-    const int nbx = N / 32, nby = (M + 31) / 32, nblocks = nbx * nby;
-    const double wb = (double)N * K * 2, ab = (double)M * K * 4;
-    const int colmaj = g_mid_colmaj < 0 ? (wb + 8 * ab < 8 * wb + ab ? 1 : 0) : g_mid_colmaj;
-    hipLaunchKernelGGL((gemm_mid_c_kernel<EPI, MID_CPW, RMAX>), dim3(nblocks), dim3(256), smem, st, A, lda, Wk, C, ldc, R, ldr, M, N, K, nbx, nblocks, colmaj, ra);
-    return hipGetLastError();
-}
 template <int TN, int EPI>
 static hipError_t launch_mid(hipStream_t st, const float* A, int lda, const uint16_t* Wk, float* C, int ldc, const float* R, int ldr, int M, int N, int K,
                              mid_rope_args ra = mid_rope_args{}) {
-    if (TN == 1 && mid_cpw_for(K >> 6)) {
-        constexpr int E = EPI == 1 ? 0 : EPI;
-        const int rounds = ((K >> 6) + 4 * MID_CPW - 1) / (4 * MID_CPW);
-        if (rounds == 1) return launch_mid_c<E, 1>(st, A, lda, Wk, C, ldc, R, ldr, M, N, K, ra);
-        if (rounds == 2) return launch_mid_c<E, 2>(st, A, lda, Wk, C, ldc, R, ldr, M, N, K, ra);
-        if (rounds == 3) return launch_mid_c<E, 3>(st, A, lda, Wk, C, ldc, R, ldr, M, N, K, ra);
-        return launch_mid_c<E, 4>(st, A, lda, Wk, C, ldc, R, ldr, M, N, K, ra);
-    }
     if (g_mid_nw == 8) return launch_mid_nw<TN, EPI, 8, true>(st, A, lda, Wk, C, ldc, R, ldr, M, N, K, ra);
     if (g_mid_nw != 0) return launch_mid_nw<TN, EPI, 4, true>(st, A, lda, Wk, C, ldc, R, ldr, M, N, K, ra);
     if (K / 64 <= 9) return launch_mid_nw<TN, EPI, 9, false>(st, A, lda, Wk, C, ldc, R, ldr, M, N, K, ra);
@@ -654,9 +433,6 @@ hipError_t cz_launch_gemm_mid_group(hipStream_t st, int nprob, const float* cons
     }
     for (int i = nprob; i <= MID_GROUP_MAX; ++i) g.tile0[i] = tiles;
     g.n = nprob;
-    bool all_c = true;                                                    // consecutive chunks per wave where EVERY problem's K is one round of them
-    for (int i = 0; i < nprob; ++i) all_c = all_c && mid_cpw_for(K[i] >> 6) && (K[i] >> 6) <= 4 * MID_CPW;
-    if (all_c) { hipLaunchKernelGGL((gemm_mid_group_c_kernel<MID_CPW>), dim3(tiles), dim3(256), (size_t)(4 * mid_c_lds<MID_CPW>::WAVE_FLOATS) * sizeof(float), st, g, M, tiles); return hipGetLastError(); }
     const size_t smem = (size_t)(4 * 32 * MID_LDK + 4) * sizeof(float);
     hipLaunchKernelGGL((gemm_mid_group_kernel<4, true>), dim3(tiles), dim3(4 * 64), smem, st, g, M, tiles);
     return hipGetLastError();

@@ -1505,7 +1505,7 @@ static cz_status set_stream_priority(cz_session* s, int prio) {
 // The process-wide knobs (the g_* globals of the kernel files) with the values they are shipped with, captured the first time any knob is
 // touched: "reset_process_knobs" puts every one of them back (the tests' fixture finalizer: a test that turned one leaves no trace for
 // the tests that run after it in the same process).
-extern int g_cdf_dec_grid_cap, g_gemm_lds_kb, g_attn_v1, g_dec_grid_target, g_dec_nw_cap, g_dec_mt_max, g_dec_norm_mfma, g_gemm_mid_rows, g_mid_nw, g_mid_colmaj, g_mid_quad, g_mid_cpw,
+extern int g_cdf_dec_grid_cap, g_gemm_lds_kb, g_attn_v1, g_dec_grid_target, g_dec_nw_cap, g_dec_mt_max, g_dec_norm_mfma, g_gemm_mid_rows, g_mid_nw, g_mid_colmaj, g_mid_quad,
            g_dec_attn_split_heads, g_dec_attn_lds_pad, g_dec_wide_rows, g_dec_attn_small_grid, g_dec_attn_split_max, g_rw_seq_rows, g_rw_state_pad;
 struct ProcKnob { const char* key; int* p; int shipped; };
 static std::vector<ProcKnob>& proc_knobs() {
@@ -1514,7 +1514,7 @@ static std::vector<ProcKnob>& proc_knobs() {
         const std::pair<const char*, int*> all[] = {
             {"cdf_dec_grid_cap", &g_cdf_dec_grid_cap}, {"gemm_lds_kb", &g_gemm_lds_kb}, {"attn_v1", &g_attn_v1}, {"dec_grid_target", &g_dec_grid_target}, {"dec_nw_cap", &g_dec_nw_cap},
             {"dec_mt_max", &g_dec_mt_max}, {"dec_norm_mfma", &g_dec_norm_mfma}, {"gemm_mid_rows", &g_gemm_mid_rows}, {"mid_nw", &g_mid_nw}, {"mid_colmaj", &g_mid_colmaj},
-            {"mid_quad", &g_mid_quad}, {"mid_cpw", &g_mid_cpw}, {"dec_attn_split_heads", &g_dec_attn_split_heads}, {"dec_attn_lds_pad", &g_dec_attn_lds_pad},
+            {"mid_quad", &g_mid_quad}, {"dec_attn_split_heads", &g_dec_attn_split_heads}, {"dec_attn_lds_pad", &g_dec_attn_lds_pad},
             {"dec_wide_rows", &g_dec_wide_rows}, {"dec_attn_small_grid", &g_dec_attn_small_grid}, {"dec_attn_split_max", &g_dec_attn_split_max},
             {"rwkv_seq_rows", &g_rw_seq_rows}, {"rw_state_pad", &g_rw_state_pad}};
         for (const auto& a : all) k.push_back({a.first, a.second, *a.second});
@@ -1552,7 +1552,6 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "mid_nw")) g_mid_nw = (int)value;
     else if (!strcmp(key, "mid_colmaj")) g_mid_colmaj = (int)value;
     else if (!strcmp(key, "mid_quad")) g_mid_quad = (int)value;
-    else if (!strcmp(key, "mid_cpw")) g_mid_cpw = (int)value;
     else if (!strcmp(key, "cdf_dec_grid_cap")) g_cdf_dec_grid_cap = (int)value;
     else if (!strcmp(key, "dec_attn_split_heads")) g_dec_attn_split_heads = (int)value;
     else if (!strcmp(key, "dec_attn_lds_pad")) g_dec_attn_lds_pad = (int)value;              // (before the first decode: the kernels' LDS limit is set once)

@@ -1,6 +1,6 @@
 """Round-4 GPU parity tests: decode-CDF blocks that own several streams (the row loop of the DECODE instantiations of cdf_par_kernel, which
-real launches never take: one block per stream), the shipped values of the process-wide knobs, the K-group GEMM with consecutive K chunks
-per wave, and a KV cache that is replaced (not grown) between two runs."""
+real launches never take: one block per stream), the shipped values of the process-wide knobs, and a KV cache that is replaced (not grown)
+between two runs."""
 import numpy as np
 import pytest
 
