@@ -107,9 +107,20 @@ hipError_t cz_launch_dec_gemm_group(hipStream_t st, int nprob, const float* cons
 hipError_t cz_launch_dec_gemm_masked(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* C, int ldc, const float* R, int M, int N, int K,
                                      const unsigned char* row_mask);
 hipError_t cz_launch_dec_gemm_relusq(hipStream_t st, const float* A, int lda, const uint16_t* Wd, float* C, int ldc, int M, int N, int K);
+// the same projections for a handful of streams (<= 4 rows) on the VALU, one wave per block (kernels_gemv.hip); A and W in NATURAL layout
+bool cz_dec_gemv_ok(int M, int K, bool norm);
+hipError_t cz_launch_dec_gemv_plain(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R, int M, int N, int K,
+                                    const uint16_t* normw, float eps);
+hipError_t cz_launch_dec_gemv_qkv(hipStream_t st, const float* A, int lda, const uint16_t* W, float* Q, int ldq, int M, int K, int n_heads, int n_kv,
+                                  const cz_rope_desc* descs, size_t kv_off, const int* pos_dev, const float* cs, const float* sn, const uint16_t* normw, float eps);
+hipError_t cz_launch_dec_gemv_swiglu(hipStream_t st, const float* A, int lda, const uint16_t* W, float* H, int ldh, int M, int f, int K, const uint16_t* normw, float eps);
 hipError_t cz_dec_attn_prepare(int max_nk);
 // split_scratch (cz_dec_attn_split_bytes(split_streams, n_heads) bytes, or null): scores / chunk maxima / P.V partials of the three-launch form
 // small groups take (kernels_decode.hip, "Split decode attention")
 hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nstreams, int max_nk,
                               int n_heads, int n_kv, size_t kv_off, const int* pos_dev, int out_kq = 1, float* split_scratch = nullptr, int split_streams = 0);
 size_t cz_dec_attn_split_bytes(int nstreams, int n_heads);
+bool cz_dec_attn_is_split(int nstreams, int max_nk, int n_heads, int n_kv, const float* split_scratch, int split_streams);
+const float* cz_dec_attn_split_partials(const float* split_scratch, int split_streams, int n_heads, int* maxc);
+hipError_t cz_launch_dec_gemv_attsum(hipStream_t st, const float* part, int part_maxc, int max_nk, const int* pos_dev, const uint16_t* W, float* C, int ldc, const float* R,
+                                     int M, int N, int n_heads);

@@ -953,11 +953,23 @@ static void da_launch(hipStream_t st, int rep, dim3 grid, size_t smem, const flo
 }
 int g_dec_attn_lds_pad = 0;         // tuning knob (cz_debug_set "dec_attn_lds_pad"): extra dynamic LDS bytes per block of the whole-device grids (fewer blocks per CU)
 int g_dec_attn_split_heads = 1;     // tuning knob (cz_debug_set "dec_attn_split_heads"): 0 = never one block per query head
+// true when cz_launch_dec_attn takes the three-launch split form for this group
+bool cz_dec_attn_is_split(int nstreams, int max_nk, int n_heads, int n_kv, const float* split_scratch, int split_streams) {
+    const int rep = n_kv > 0 ? n_heads / n_kv : 0;
+    return rep >= 1 && rep <= DA_MAXREP && split_scratch && nstreams <= split_streams && max_nk <= DA_SPLIT_MAXC * 64 && nstreams * n_heads <= g_dec_attn_split_max;
+}
+// the P.V chunk partials of the split form inside split_scratch: [nstreams][n_heads][DA_SPLIT_MAXC][64] (cz_launch_dec_gemv_attsum adds them up)
+const float* cz_dec_attn_split_partials(const float* split_scratch, int split_streams, int n_heads, int* maxc) {
+    *maxc = DA_SPLIT_MAXC;
+    return split_scratch + (size_t)split_streams * n_heads * DA_SPLIT_MAXC * 64 + (size_t)split_streams * n_heads * DA_SPLIT_MAXC;
+}
+// out_kq = -1 (split form only): the ordered sum of the chunk partials is left to the consumer (the o-projection of kernels_gemv.hip): O is not written
 hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nstreams, int max_nk,
                               int n_heads, int n_kv, size_t kv_off, const int* pos_dev, int out_kq, float* split_scratch, int split_streams) {
     if (nstreams <= 0) return hipSuccess;
     const int rep = n_heads / n_kv;
     if (rep < 1 || rep > DA_MAXREP || max_nk > CZ_KERNEL_MAX_CTX) return hipErrorInvalidValue;
+    if (out_kq < 0 && !cz_dec_attn_is_split(nstreams, max_nk, n_heads, n_kv, split_scratch, split_streams)) return hipErrorInvalidValue;
     if (split_scratch && nstreams <= split_streams && max_nk <= DA_SPLIT_MAXC * 64 && nstreams * n_heads <= g_dec_attn_split_max) {
         float* SC = split_scratch;
         float* CM = SC + (size_t)split_streams * n_heads * DA_SPLIT_MAXC * 64;
@@ -965,7 +977,7 @@ hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O,
         const int nchm = (max_nk + 63) / 64;
         hipLaunchKernelGGL(da_split_scores_kernel, dim3(nstreams, n_heads, nchm), dim3(64), 0, st, Q, ldq, descs, n_heads, rep, kv_off, pos_dev, SC, CM);
         hipLaunchKernelGGL(da_split_pv_kernel, dim3(nstreams, n_heads, nchm), dim3(64), 0, st, descs, n_heads, rep, kv_off, pos_dev, SC, CM, PART);
-        hipLaunchKernelGGL(da_split_sum_kernel, dim3(nstreams, n_heads), dim3(64), 0, st, descs, n_heads, pos_dev, PART, O, ldo, out_kq);
+        if (out_kq >= 0) hipLaunchKernelGGL(da_split_sum_kernel, dim3(nstreams, n_heads), dim3(64), 0, st, descs, n_heads, pos_dev, PART, O, ldo, out_kq);
         return hipGetLastError();
     }
     const int ss = da_s_stride(max_nk);

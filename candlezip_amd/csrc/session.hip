@@ -40,6 +40,7 @@ extern int g_dec_attn_small_grid;
 extern int g_dec_attn_split_max;
 extern int g_rw_seq_rows;
 extern int g_rw_state_pad;
+extern int g_gemv_fold_attn;
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t _e = (expr);                                                                        \
@@ -503,6 +504,48 @@ static cz_status llama_step_fast(cz_session* s, int B, int pos, int max_nk) {
     s->prof_end(2.0 * B * (double)c.vocab * d, (double)c.vocab * d * 2 + (double)B * c.vocab * 4);
     return CZ_OK;
 }
+// The same step for a HANDFUL of streams (the CLI's one stream per file): every projection on the VALU kernels of kernels_gemv.hip — one wave per
+// block, no block barrier, one memory round trip per launch — with natural-layout activations; attention as in llama_step_fast.  Five launches per
+// layer (the norms ride in the QKV / gate|up / lm_head projections).  Same canonical chains, same bits.
+static cz_status llama_step_gemv(cz_session* s, int B, int pos, int max_nk) {
+    const LlamaModel& m = s->llama; const cz_llama_config& c = m.cfg;
+    const int d = c.d_model, f = c.d_ffn;
+    CZCHK(s->x.ensure((size_t)B * d * 4)); CZCHK(s->qkv.ensure((size_t)B * d * 4)); CZCHK(s->gu.ensure((size_t)B * d * 4)); CZCHK(s->h.ensure((size_t)B * f * 4));
+    float *x = (float*)s->x.p, *q = (float*)s->qkv.p, *att = (float*)s->gu.p, *h = (float*)s->h.p;
+    hipStream_t st = s->stream;
+    s->prof_begin(PK_EMBED); HIPCHK(cz_launch_embed(st, (const uint32_t*)s->tok.p, m.E, x, B, d)); s->prof_end(0, (double)B * d * 6);
+    const int kvd = c.n_kv_heads * 64, nq = d + 2 * kvd;
+    for (int l = 0; l < c.n_layers; ++l) {
+        const LlamaModel::Layer& y = m.L[l];
+        const size_t kv_off = (size_t)l * s->kv_layer_stride;
+        if (!(s->dbg_skip & 2)) {
+            s->prof_begin(PK_DEC_GEMM_QKV);
+            HIPCHK(cz_launch_dec_gemv_qkv(st, x, d, y.wqkv, q, d, B, d, c.n_heads, c.n_kv_heads, s->step_roped, kv_off, s->pos_dev, m.rope_cos, m.rope_sin, y.ln1, c.rms_eps));
+            s->prof_end(2.0 * B * (double)nq * d, (double)nq * d * 2);
+        }
+        // the split (three-launch) attention of a handful of streams leaves the ordered sum of its chunk partials to the o-projection: one launch less per layer
+        const bool fold = g_gemv_fold_attn && !s->dbg_skip && d <= 768 && cz_dec_attn_is_split(B, max_nk, c.n_heads, c.n_kv_heads, s->attn_split, s->attn_split_streams);
+        if (!(s->dbg_skip & 1)) {
+            s->prof_begin(PK_DEC_ATTN);
+            HIPCHK(cz_launch_dec_attn(st, q, d, att, d, s->step_seqd, B, max_nk, c.n_heads, c.n_kv_heads, kv_off, s->pos_dev, fold ? -1 : 0, s->attn_split, s->attn_split_streams));
+            s->prof_end(4.0 * 64 * c.n_heads * (double)B * (pos + 1), 2.0 * B * (double)(pos + 1) * kvd * 4);
+        }
+        if (s->dbg_skip & 2) continue;
+        s->prof_begin(PK_DEC_GEMM);
+        if (fold) {
+            int maxc = 0;
+            const float* part = cz_dec_attn_split_partials(s->attn_split, s->attn_split_streams, c.n_heads, &maxc);
+            HIPCHK(cz_launch_dec_gemv_attsum(st, part, maxc, max_nk, s->pos_dev, y.wo, x, d, x, B, d, c.n_heads));
+        } else HIPCHK(cz_launch_dec_gemv_plain(st, att, d, y.wo, x, d, x, B, d, d, nullptr, 0.0f));
+        s->prof_end(2.0 * B * (double)d * d, (double)d * d * 2);
+        s->prof_begin(PK_DEC_GEMM_GU); HIPCHK(cz_launch_dec_gemv_swiglu(st, x, d, y.wgu, h, f, B, f, d, y.ln2, c.rms_eps)); s->prof_end(4.0 * B * (double)f * d, (double)f * d * 4);
+        s->prof_begin(PK_DEC_GEMM); HIPCHK(cz_launch_dec_gemv_plain(st, h, f, y.wd, x, d, x, B, d, f, nullptr, 0.0f)); s->prof_end(2.0 * B * (double)d * f, (double)d * f * 2);
+    }
+    s->prof_begin(PK_DEC_GEMM_HEAD);
+    HIPCHK(cz_launch_dec_gemv_plain(st, x, d, m.E, s->step_logits, c.vocab, nullptr, B, c.vocab, d, m.lnf, c.rms_eps));
+    s->prof_end(2.0 * B * (double)c.vocab * d, (double)c.vocab * d * 2 + (double)B * c.vocab * 4);
+    return CZ_OK;
+}
 // The same step for ONE WIDE lock-step group (a few hundred to 1024 streams): the projections go through the LDS-tiled MFMA GEMM with
 // 64-row tiles instead of the latency-oriented dec_gemm_kernel (whose blocks re-read the activations once per 32 output columns and
 // reach 10-30 % of the MFMA rate at these row counts); attention is the same dec_attn_kernel (natural-layout output), HBM-bound on the
@@ -587,6 +630,7 @@ static cz_status llama_step_wide(cz_session* s, int B, int pos, int max_nk) {
 // the lock-step decode step: the latency-oriented kernels for narrow groups, the tiled-GEMM chain for wide ones
 static cz_status llama_step_any(cz_session* s, int B, int pos, int max_nk) {
     if (s->wide_min_streams > 0 && B >= s->wide_min_streams) return llama_step_wide(s, B, pos, max_nk);
+    if (cz_dec_gemv_ok(B, s->llama.cfg.d_model, true) && cz_dec_gemv_ok(B, s->llama.cfg.d_ffn, false)) return llama_step_gemv(s, B, pos, max_nk);
     return llama_step_fast(s, B, pos, max_nk);
 }
 // one token per stream at position `pos` (tokens in s->tok[0..B)); logits -> s->step_logits [B][V]
@@ -1505,14 +1549,14 @@ static cz_status set_stream_priority(cz_session* s, int prio) {
 // The process-wide knobs (the g_* globals of the kernel files) with the values they are shipped with, captured the first time any knob is
 // touched: "reset_process_knobs" puts every one of them back (the tests' fixture finalizer: a test that turned one leaves no trace for
 // the tests that run after it in the same process).
-extern int g_cdf_dec_grid_cap, g_gemm_lds_kb, g_attn_v1, g_dec_grid_target, g_dec_nw_cap, g_dec_mt_max, g_dec_norm_mfma, g_gemm_mid_rows, g_mid_nw, g_mid_colmaj, g_mid_quad,
+extern int g_gemv_max_rows, g_gemv_fold_attn, g_cdf_dec_grid_cap, g_gemm_lds_kb, g_attn_v1, g_dec_grid_target, g_dec_nw_cap, g_dec_mt_max, g_dec_norm_mfma, g_gemm_mid_rows, g_mid_nw, g_mid_colmaj, g_mid_quad,
            g_dec_attn_split_heads, g_dec_attn_lds_pad, g_dec_wide_rows, g_dec_attn_small_grid, g_dec_attn_split_max, g_rw_seq_rows, g_rw_state_pad;
 struct ProcKnob { const char* key; int* p; int shipped; };
 static std::vector<ProcKnob>& proc_knobs() {
     static std::vector<ProcKnob> k;
     if (k.empty()) {
         const std::pair<const char*, int*> all[] = {
-            {"cdf_dec_grid_cap", &g_cdf_dec_grid_cap}, {"gemm_lds_kb", &g_gemm_lds_kb}, {"attn_v1", &g_attn_v1}, {"dec_grid_target", &g_dec_grid_target}, {"dec_nw_cap", &g_dec_nw_cap},
+            {"gemv_max_rows", &g_gemv_max_rows}, {"gemv_fold_attn", &g_gemv_fold_attn}, {"cdf_dec_grid_cap", &g_cdf_dec_grid_cap}, {"gemm_lds_kb", &g_gemm_lds_kb}, {"attn_v1", &g_attn_v1}, {"dec_grid_target", &g_dec_grid_target}, {"dec_nw_cap", &g_dec_nw_cap},
             {"dec_mt_max", &g_dec_mt_max}, {"dec_norm_mfma", &g_dec_norm_mfma}, {"gemm_mid_rows", &g_gemm_mid_rows}, {"mid_nw", &g_mid_nw}, {"mid_colmaj", &g_mid_colmaj},
             {"mid_quad", &g_mid_quad}, {"dec_attn_split_heads", &g_dec_attn_split_heads}, {"dec_attn_lds_pad", &g_dec_attn_lds_pad},
             {"dec_wide_rows", &g_dec_wide_rows}, {"dec_attn_small_grid", &g_dec_attn_small_grid}, {"dec_attn_split_max", &g_dec_attn_split_max},
@@ -1553,6 +1597,8 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "mid_colmaj")) g_mid_colmaj = (int)value;
     else if (!strcmp(key, "mid_quad")) g_mid_quad = (int)value;
     else if (!strcmp(key, "cdf_dec_grid_cap")) g_cdf_dec_grid_cap = (int)value;
+    else if (!strcmp(key, "gemv_max_rows")) g_gemv_max_rows = (int)value;
+    else if (!strcmp(key, "gemv_fold_attn")) g_gemv_fold_attn = (int)value;
     else if (!strcmp(key, "dec_attn_split_heads")) g_dec_attn_split_heads = (int)value;
     else if (!strcmp(key, "dec_attn_lds_pad")) g_dec_attn_lds_pad = (int)value;              // (before the first decode: the kernels' LDS limit is set once)
     else if (!strcmp(key, "dec_wide_rows")) g_dec_wide_rows = (int)value;

@@ -169,7 +169,7 @@ def _eq(a, b, what):
     assert n == 0, f"{what}: {n}/{a.size} logits differ"
 
 
-@pytest.mark.parametrize("path", ["tiled", "np2", "hybrid", "mid", "mid_q0", "mid8", "mid9"])
+@pytest.mark.parametrize("path", ["tiled", "np2", "hybrid", "mid", "mid_q0", "mid8", "mid9", "gemv"])
 @pytest.mark.parametrize("shape", ["tiny", "135m"])
 def test_wide_group_step_is_bitexact(cz, czo, shape, path):
     """the decode step of ONE WIDE lock-step group against the oracle: every logit of the trait steps, the coder intervals, and a lock-step
@@ -178,13 +178,16 @@ def test_wide_group_step_is_bitexact(cz, czo, shape, path):
     "hybrid" = tiled QKV / lm_head projections, the rest on the 32 x 64 blocks; "mid" = gemm_mid_kernel (32 x 32 tiles, four K groups per
     block, ordered hand-off of the chunk partials, RoPE + cache write in the QKV epilogue) for the layer projections — the four waves sharing
     the ordered sum and the epilogue by register quads ("mid", round 3) or wave 0 doing both ("mid_q0"); "mid8" / "mid9" = the
-    same with eight K groups / one wave per 64-chunk (nine for K = 576, twelve in two rounds for K = 1536): the `mid_nw` tuning knob"""
+    same with eight K groups / one wave per 64-chunk (nine for K = 576, twelve in two rounds for K = 1536): the `mid_nw` tuning knob; "gemv" (round 4) =
+    the VALU projections groups of <= 4 streams take by default (kernels_gemv.hip: one wave per block, fused norms): the trait steps and lock-step
+    decodes of 1, 2, 3 and 4 streams — every other path runs with them switched off (`gemv_max_rows` = 0), so that its own kernels serve the single-stream steps too"""
     if shape == "tiny":
         gcfg, ocfg, V, n_tok, seed = cz.tiny_llama_config(), czo.tiny_llama_config(), 512, 700, 11
     else:
         gcfg, ocfg, V, n_tok, seed = cz.smollm2_135m_config(), czo.smollm2_135m_config(), 49152, 40, 0x5EED
     g = cz.Session("smollm", gcfg, seed=seed, embed_std=0.05 if shape == "tiny" else 0.02, max_streams=6)
     o = czo.SmolLmSession(ocfg, seed=seed, embed_std=0.05 if shape == "tiny" else 0.02)
+    g.debug_set("gemv_max_rows", 4 if path == "gemv" else 0)
     g.debug_set("dec_attn_split_max", 0 if path in ("tiled", "np2", "hybrid", "mid8") else 128)   # small groups: the one-kernel forms below (0) / the three-launch split form (round 3)
     g.debug_set("dec_attn_small_grid", 0 if path in ("tiled", "np2") else 128)   # decode attention with 8 waves per block (whole-device grids) / 16 (small grids)
     g.debug_set("dec_attn_split_heads", 0 if path == "hybrid" else 1)            # small grids: a block per kv head (0) / per query head (1, the default)
@@ -195,6 +198,8 @@ def test_wide_group_step_is_bitexact(cz, czo, shape, path):
         g.debug_set("wide_min_streams", 1); g.debug_set("wide_mode", 3)
         g.debug_set("mid_nw", {"mid": 4, "mid_q0": 4, "mid8": 8, "mid9": 0}[path])     # (process-wide knob: reset by conftest)
         g.debug_set("mid_quad", 0 if path == "mid_q0" else 1)             # four-wave blocks: wave 0 alone sums and runs the epilogue (0) / all four waves share both (1, the default)
+    elif path == "gemv":
+        pass                                                              # the shipped narrow-group configuration
     elif path == "hybrid":                                                # tiled QKV / lm_head, dec_gemm 32 x 64 blocks for the other projections
         g.debug_set("wide_min_streams", 1); g.debug_set("wide_mode", 2); g.debug_set("dec_wide_rows", 1)
     else:
@@ -221,6 +226,14 @@ def test_wide_group_step_is_bitexact(cz, czo, shape, path):
         for s_, out, (_, z) in zip(streams, outs, coded):
             if z == 0:
                 assert np.array_equal(out, s_)
+        if path == "gemv":                                                # groups of 1..4 streams: the one-, two- and four-row instantiations (three rows: a ragged four)
+            for nb in (1, 2, 3, 4):
+                g.debug_set("gemv_fold_attn", nb & 1)                      # the split attention's ordered sum inside the o-projection (the default) / as its own launch
+                outs = g.decode_tokens_batch([p for p, _ in coded[:nb]], lens[:nb])
+                assert np.array_equal(outs[0], o.decode_tokens(ref[0][0], lens[0])), nb
+                for s_, out, (_, z) in zip(streams[:nb], outs, coded[:nb]):
+                    if z == 0:
+                        assert np.array_equal(out, s_), nb
     # (the process-wide knobs touched above go back to their shipped values in conftest's fixture finalizer)
     g.close(); o.close()
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Tuning aid: lock-step decode steps at a FIXED context length, on one or several concurrent lanes (cz_debug_decode_steps).
 Each config is `name:B=<streams per lane>,L=<lanes>,pos=<context>,x=<0|1: one XCD per lane via a CU-masked stream>,av=<dbg_skip: 1 = no attention, 2 = attention only>,
-fn=<fuse_norm>,gt=<dec_grid_target>,dw=<dec_wide_rows: dec_gemm blocks of 32 x 64 from this many rows on>,wm=<wide_min_streams: groups at least this wide take the tiled-GEMM step>,nw=<mid_nw: K groups of gemm_mid, 0 = by K>,mq=<mid_quad>,sp=<dec_attn_split_max>,pad=<dec_attn_lds_pad: extra LDS bytes per decode-attention block>,mt=<dec_mt_max>,g=<1 graph|0 eager>,prof=<1: eager per-family HIP events on lane 0>`.  Prints one JSON line per config."""
+fn=<fuse_norm>,gt=<dec_grid_target>,dw=<dec_wide_rows: dec_gemm blocks of 32 x 64 from this many rows on>,wm=<wide_min_streams: groups at least this wide take the tiled-GEMM step>,nw=<mid_nw: K groups of gemm_mid, 0 = by K>,mq=<mid_quad>,sp=<dec_attn_split_max>,gv=<gemv_max_rows: groups of at most this many streams take the VALU projections, 0 = never>,pad=<dec_attn_lds_pad: extra LDS bytes per decode-attention block>,mt=<dec_mt_max>,g=<1 graph|0 eager>,prof=<1: eager per-family HIP events on lane 0>`.  Prints one JSON line per config."""
 import argparse
 import ctypes as C
 import json
@@ -77,13 +77,14 @@ def main():
     parent = cz.Session("smollm", cz.smollm2_135m_config(), seed=0x5EED, embed_std=0.02, max_streams=args.max_streams)
     for c in args.configs:
         name, _, kv = c.partition(":")
-        d = dict(B=128, L=1, pos=767, x=0, av=0, fn=0, g=1, prof=0, gt=384, mt=8, wm=256, dw=256, wmode=1, nw=4, pad=0, mq=1, sp=36, av1=-1, pr0=0, pr1=0)
+        d = dict(B=128, L=1, pos=767, x=0, av=0, fn=0, g=1, prof=0, gt=384, mt=8, wm=256, dw=256, wmode=1, nw=4, pad=0, mq=1, sp=36, av1=-1, pr0=0, pr1=0, gv=4, fa=1)
         for item in kv.split(","):
             if item:
                 k, v = item.split("=")
                 d[k] = int(v)
         parent.debug_set("dec_grid_target", d["gt"]); parent.debug_set("dec_mt_max", d["mt"])     # (process-wide knobs)
         WM[0] = d["wm"]; WM[1] = d["wmode"]; parent.debug_set("dec_wide_rows", d["dw"]); parent.debug_set("mid_nw", d["nw"]); parent.debug_set("dec_attn_lds_pad", d["pad"])
+        parent.debug_set("gemv_max_rows", d["gv"]); parent.debug_set("gemv_fold_attn", d["fa"])      # fa: the o-projection adds up the split attention's partials
         parent.debug_set("mid_quad", d["mq"]); parent.debug_set("dec_attn_split_max", d["sp"])     # mq: gemm_mid blocks share sum + epilogue over their waves; sp: split attention up to this many (stream, head) pairs
         run_config(parent, None, name + f"[gt={d['gt']}]", d["B"], d["L"], d["pos"], d["x"], d["av"], d["fn"], d["g"], d["prof"], args.iters, args.sym, d["av1"], d["pr0"], d["pr1"])
     parent.close()
