@@ -114,6 +114,10 @@ hipError_t cz_launch_dec_gemv_plain(hipStream_t st, const float* A, int lda, con
 hipError_t cz_launch_dec_gemv_qkv(hipStream_t st, const float* A, int lda, const uint16_t* W, float* Q, int ldq, int M, int K, int n_heads, int n_kv,
                                   const cz_rope_desc* descs, size_t kv_off, const int* pos_dev, const float* cs, const float* sn, const uint16_t* normw, float eps);
 hipError_t cz_launch_dec_gemv_swiglu(hipStream_t st, const float* A, int lda, const uint16_t* W, float* H, int ldh, int M, int f, int K, const uint16_t* normw, float eps);
+hipError_t cz_launch_dec_gemv_relusq(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, int M, int N, int K);
+hipError_t cz_launch_dec_gemv_masked(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, int M, int N, int K, const unsigned char* row_mask);
+hipError_t cz_launch_dec_gemv_group(hipStream_t st, int nprob, const float* const* A, const int* lda, const uint16_t* const* W, float* const* C, const int* ldc,
+                                    const int* N, const int* K, int M);
 hipError_t cz_dec_attn_prepare(int max_nk);
 // split_scratch (cz_dec_attn_split_bytes(split_streams, n_heads) bytes, or null): scores / chunk maxima / P.V partials of the three-launch form
 // small groups take (kernels_decode.hip, "Split decode attention")

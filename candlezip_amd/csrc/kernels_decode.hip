@@ -556,6 +556,9 @@ typedef __attribute__((address_space(1))) const float gfloat;     // K/V pointer
 #ifndef CZ_DA_VPRE
 #define CZ_DA_VPRE 1         // the whole-device form requests its first V round before the softmax phases (tuning build `make da_vpre0`: 0 = not)
 #endif
+#ifndef CZ_DA_VPRE_KEYS
+#define CZ_DA_VPRE_KEYS 16   // keys of that first V round (tuning build `make da_vpre32`: 32)
+#endif
 #ifndef CZ_DA_OCC
 #define CZ_DA_OCC 4          // waves per SIMD the whole-device form is compiled for (tuning build `make da_occ6`: 6 = three blocks per CU, 80 VGPRs)
 #endif
@@ -647,7 +650,7 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : (DA_WAVES == 8 ? 
     // barriers (the bit pattern of what is loaded does not depend on them); phase 3 then starts on resident data
     // The whole-device form (two blocks per CU) requests the first 16-key round of that slab: enough to keep loads in flight through the softmax
     // phases, whose barriers otherwise leave this block's share of the memory pipe empty (CZ_DA_VPRE = 0: off)
-    constexpr int VPRE = DEEP ? 64 : ((!LONG && DA_WAVES == 8 && CZ_DA_VPRE) ? 16 : 0);
+    constexpr int VPRE = DEEP ? 64 : ((!LONG && DA_WAVES == 8 && CZ_DA_VPRE) ? CZ_DA_VPRE_KEYS : 0);
     float vpre[VPRE ? VPRE : 1];
     if (VPRE) {
         const int c = wave;

@@ -20,13 +20,14 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-enum { GV_PLAIN = 0, GV_ROPE = 1, GV_SWIGLU = 2 };
+enum { GV_PLAIN = 0, GV_ROPE = 1, GV_SWIGLU = 2, GV_RELUSQ = 3 };      // GV_RELUSQ: C = relu(A.W^T)^2 (the RWKV7 channel-mix key projection, rwkv7.rs:426)
 #define GV_CS 68                            // floats per 64-chunk of an activation row in LDS
 struct gemv_args {
     const float* A; int lda;                // natural layout [M][K] (NORM: the residual stream, RMSNorm(normw, eps) applied on the way)
     const uint16_t* W;                      // natural bf16 [N][K]; GV_SWIGLU: [gate rows (f) | up rows (f)]
     int M, N, K;
     float* C; int ldc; const float* R;      // GV_PLAIN: C = A.W^T (+ R, may alias C); GV_SWIGLU: C [M][f] = silu(gate) * up; GV_ROPE: q -> C
+    const unsigned char* row_mask;          // GV_PLAIN: rows with mask == 0 are not stored (RWKV literal symbols do not step the model)
     const uint16_t* normw; float eps;
     int n_heads, n_kv; const cz_rope_desc* descs; size_t kv_off; const int* pos_dev; const float* cs; const float* sn;   // GV_ROPE
     int nunits;                             // PLAIN: N columns; ROPE: N / 2 pairs; SWIGLU: f pairs
@@ -36,10 +37,10 @@ struct gemv_args {
     const float* part; int part_maxc;
 };
 
-template <int EPI, bool NORM, int MB, int CPL, int ASUM = 0>
-__global__ __launch_bounds__(64) void dec_gemv_kernel(gemv_args a) {
+template <int EPI, bool NORM, int MB, int CPL, int ASUM, int XRP>
+__device__ __forceinline__ void dec_gemv_body(const gemv_args& a, const int bx, const int by) {
     static_assert(ASUM == 0 || (EPI == GV_PLAIN && !NORM && MB == 1 && CPL == 1), "ASUM: the o-projection of one row per block");
-    constexpr int NC = EPI == GV_PLAIN ? 1 : 2;
+    constexpr int NC = (EPI == GV_PLAIN || EPI == GV_RELUSQ) ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
     const int K = a.K, nk = K >> 6, LPC = (nk + CPL - 1) / CPL, upw = 64 / LPC;
@@ -49,12 +50,12 @@ __global__ __launch_bounds__(64) void dec_gemv_kernel(gemv_args a) {
     float* ssq = part + 64 * CPL * NC * MB;                    // [MB][nk] chunk sums of squares (NORM)
     const int ul = lane / LPC, cg = lane - ul * LPC;
     const bool lane_on = ul < upw;
-    const int unit_raw = blockIdx.x * upw + ul;
+    const int unit_raw = bx * upw + ul;
     const bool unit_on = lane_on && unit_raw < a.nunits;
     const int unit = unit_raw < a.nunits ? unit_raw : a.nunits - 1;     // (clamped: idle lanes load what a neighbour loads, never a conditional load)
-    const int m0 = blockIdx.y * MB;
+    const int m0 = by * MB;
     int n[NC];
-    if (EPI == GV_PLAIN) n[0] = unit;
+    if (NC == 1) n[0] = unit;
     else if (EPI == GV_ROPE) { n[0] = (unit >> 5) * 64 + (unit & 31); n[NC - 1] = n[0] + 32; }
     else { n[0] = unit; n[NC - 1] = a.N / 2 + unit; }
     // ---- everything that depends on no result, requested now: the lane's weights, the epilogue's operands, the activation rows
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(64) void dec_gemv_kernel(gemv_args a) {
         pos = a.pos_dev ? *a.pos_dev : rd[0].pos0;
         rc = a.cs[(size_t)pos * 32 + (unit & 31)]; rs = a.sn[(size_t)pos * 32 + (unit & 31)];
     }
-    constexpr int XR = CPL == 1 ? 12 : 24;                     // activation elements per lane and row (launcher: nk <= 12 at CPL 1, <= 24 at CPL 3)
+    constexpr int XR = XRP ? XRP : (CPL == 1 ? 12 : 24);       // activation elements per lane and row (launcher: nk <= 12 at CPL 1, <= 24 / 48 at CPL 3)
     float xv[MB][XR];
     float nw[NORM ? XR : 1];
     if (ASUM) {
@@ -205,7 +206,11 @@ __global__ __launch_bounds__(64) void dec_gemv_kernel(gemv_args a) {
         if (row >= a.M) break;
         const float t0 = tot[0][r], t1 = tot[NC - 1][r];
         if (EPI == GV_PLAIN) {
+            if (a.row_mask && !a.row_mask[row]) continue;
             a.C[(size_t)row * a.ldc + n[0]] = a.R ? t0 + res[r] : t0;
+        } else if (EPI == GV_RELUSQ) {
+            const float z = t0 > 0.0f ? t0 : 0.0f;
+            a.C[(size_t)row * a.ldc + n[0]] = z * z;
         } else if (EPI == GV_SWIGLU) {
             a.C[(size_t)row * a.ldc + unit] = cz_siluf(t0) * t1;                        // silu(gate) * up (llama.rs MLP)
         } else {
@@ -231,24 +236,45 @@ __global__ __launch_bounds__(64) void dec_gemv_kernel(gemv_args a) {
     }
 }
 
+template <int EPI, bool NORM, int MB, int CPL, int ASUM = 0, int XRP = 0>
+__global__ __launch_bounds__(64) void dec_gemv_kernel(gemv_args a) { dec_gemv_body<EPI, NORM, MB, CPL, ASUM, XRP>(a, blockIdx.x, blockIdx.y); }
+// Several independent plain projections of one step in ONE launch (blockIdx.z = problem; K <= 768 each): the RWKV7 time-mix's seven
+// projections of differently mixed inputs, then its four LoRA up-projections.  Blocks past a problem's own unit count leave at once.
+#define GV_GROUP_MAX 8
+struct gemv_group { gemv_args p[GV_GROUP_MAX]; };
+template <int MB>
+__global__ __launch_bounds__(64) void dec_gemv_group_kernel(gemv_group g) {
+    const gemv_args& a = g.p[blockIdx.z];
+    const int nk = a.K >> 6, upw = 64 / nk;
+    if ((int)blockIdx.x * upw >= a.nunits) return;
+    dec_gemv_body<GV_PLAIN, false, MB, 1, 0, 0>(a, blockIdx.x, blockIdx.y);
+}
+
 int g_gemv_fold_attn = 1;       // tuning knob (cz_debug_set "gemv_fold_attn"): 1 = the o-projection adds up the split attention's chunk partials itself (no da_split_sum_kernel launch)
 int g_gemv_max_rows = 4;         // tuning knob (cz_debug_set "gemv_max_rows"): groups of at most this many streams take the VALU projections (0 = never)
 bool cz_dec_gemv_ok(int M, int K, bool norm) {
-    if (g_gemv_max_rows <= 0 || M > g_gemv_max_rows || M > 4 || K % 64 || K > 1536) return false;
+    if (g_gemv_max_rows <= 0 || M > g_gemv_max_rows || M > 4 || K % 64 || K > 3072) return false;
     return !norm || 4 * (K >> 6) <= 64;
 }
-template <int EPI, bool NORM, int MB, int CPL>
+template <int EPI, bool NORM, int MB, int CPL, int ASUM = 0, int XRP = 0>
 static hipError_t gemv_launch_one(hipStream_t st, gemv_args a) {
-    constexpr int NC = EPI == GV_PLAIN ? 1 : 2;
+    constexpr int NC = (EPI == GV_PLAIN || EPI == GV_RELUSQ) ? 1 : 2;
     const int nk = a.K >> 6, LPC = (nk + CPL - 1) / CPL, upw = 64 / LPC;
     const size_t smem = (size_t)(MB * nk * GV_CS + 64 * CPL * NC * MB + MB * nk) * sizeof(float);
-    hipLaunchKernelGGL((dec_gemv_kernel<EPI, NORM, MB, CPL>), dim3((a.nunits + upw - 1) / upw, (a.M + MB - 1) / MB), dim3(64), smem, st, a);
+    hipLaunchKernelGGL((dec_gemv_kernel<EPI, NORM, MB, CPL, ASUM, XRP>), dim3((a.nunits + upw - 1) / upw, (a.M + MB - 1) / MB), dim3(64), smem, st, a);
     return hipGetLastError();
 }
 template <int EPI, bool NORM>
 static hipError_t gemv_launch(hipStream_t st, const gemv_args& a) {
     // one chunk per lane up to twelve chunks (K = 576: nine lanes per unit, seven units per wave), three from there on (K = 1536: eight lanes, eight units)
-    const bool three = (a.K >> 6) > 12;
+    const int nk = a.K >> 6;
+    if (nk > 24) {                                            // K = 3072 (the RWKV7 channel-mix value projection): sixteen lanes per unit, 48 row elements per lane
+        if (EPI != GV_PLAIN || NORM) return hipErrorInvalidValue;
+        if (a.M <= 1) return gemv_launch_one<GV_PLAIN, false, 1, 3, 0, 48>(st, a);
+        if (a.M <= 2) return gemv_launch_one<GV_PLAIN, false, 2, 3, 0, 48>(st, a);
+        return gemv_launch_one<GV_PLAIN, false, 4, 3, 0, 48>(st, a);
+    }
+    const bool three = nk > 12;
     if (a.M <= 1) return three ? gemv_launch_one<EPI, NORM, 1, 3>(st, a) : gemv_launch_one<EPI, NORM, 1, 1>(st, a);
     if (a.M <= 2) return three ? gemv_launch_one<EPI, NORM, 2, 3>(st, a) : gemv_launch_one<EPI, NORM, 2, 1>(st, a);
     return three ? gemv_launch_one<EPI, NORM, 4, 3>(st, a) : gemv_launch_one<EPI, NORM, 4, 1>(st, a);
@@ -290,4 +316,40 @@ hipError_t cz_launch_dec_gemv_swiglu(hipStream_t st, const float* A, int lda, co
     if (!cz_dec_gemv_ok(M, K, normw != nullptr)) return hipErrorInvalidValue;
     gemv_args a{}; a.A = A; a.lda = lda; a.W = W; a.M = M; a.N = 2 * f; a.K = K; a.C = H; a.ldc = ldh; a.normw = normw; a.eps = eps; a.nunits = f;
     return normw ? gemv_launch<GV_SWIGLU, true>(st, a) : gemv_launch<GV_SWIGLU, false>(st, a);
+}
+// C[M][N] = relu(A . W^T)^2
+hipError_t cz_launch_dec_gemv_relusq(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, int M, int N, int K) {
+    if (M <= 0) return hipSuccess;
+    if (!cz_dec_gemv_ok(M, K, false) || K > 1536) return hipErrorInvalidValue;
+    gemv_args a{}; a.A = A; a.lda = lda; a.W = W; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc; a.nunits = N;
+    return gemv_launch<GV_RELUSQ, false>(st, a);
+}
+// rows with row_mask == 0 keep what C held
+hipError_t cz_launch_dec_gemv_masked(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, int M, int N, int K, const unsigned char* row_mask) {
+    if (M <= 0) return hipSuccess;
+    if (!cz_dec_gemv_ok(M, K, false)) return hipErrorInvalidValue;
+    gemv_args a{}; a.A = A; a.lda = lda; a.W = W; a.M = M; a.N = N; a.K = K; a.C = C; a.ldc = ldc; a.nunits = N; a.row_mask = row_mask;
+    return gemv_launch<GV_PLAIN, false>(st, a);
+}
+// nprob plain projections C_i[M][N_i] = A_i . W_i^T sharing M (K_i <= 768, W_i rows ldw_i apart), one launch
+hipError_t cz_launch_dec_gemv_group(hipStream_t st, int nprob, const float* const* A, const int* lda, const uint16_t* const* W, float* const* C, const int* ldc,
+                                    const int* N, const int* K, int M) {
+    if (M <= 0 || nprob <= 0) return hipSuccess;
+    if (nprob > GV_GROUP_MAX) return hipErrorInvalidValue;
+    gemv_group g{};
+    int gx = 0, nkmax = 0;
+    for (int i = 0; i < nprob; ++i) {
+        if (!cz_dec_gemv_ok(M, K[i], false) || K[i] > 768) return hipErrorInvalidValue;
+        gemv_args& a = g.p[i];
+        a.A = A[i]; a.lda = lda[i]; a.W = W[i]; a.M = M; a.N = N[i]; a.K = K[i]; a.C = C[i]; a.ldc = ldc[i]; a.nunits = N[i];
+        const int nk = K[i] >> 6, upw = 64 / nk, b = (N[i] + upw - 1) / upw;
+        gx = b > gx ? b : gx; nkmax = nk > nkmax ? nk : nkmax;
+    }
+    const int MB = M <= 1 ? 1 : (M <= 2 ? 2 : 4);
+    const size_t smem = (size_t)(MB * nkmax * GV_CS + 64 * MB + MB * nkmax) * sizeof(float);
+    const dim3 grid(gx, (M + MB - 1) / MB, nprob);
+    if (MB == 1) hipLaunchKernelGGL((dec_gemv_group_kernel<1>), grid, dim3(64), smem, st, g);
+    else if (MB == 2) hipLaunchKernelGGL((dec_gemv_group_kernel<2>), grid, dim3(64), smem, st, g);
+    else hipLaunchKernelGGL((dec_gemv_group_kernel<4>), grid, dim3(64), smem, st, g);
+    return hipGetLastError();
 }

@@ -538,7 +538,7 @@ static cz_status rw_step_narrow(cz_session* s, int B) {
 // The same step for ONE WIDE lock-step group (B >= rwkv_wide_min streams): natural-layout activations and the LDS-tiled MFMA GEMM for
 // every projection instead of dec_gemm_kernel's 16-row blocks (which re-read the activations once per 32 output columns); the LoRA
 // activations share one [B][320] row so that the four up-projections read slices of it.  Same canonical arithmetic, same bits.
-static cz_status rw_step_wide(cz_session* s, int B) {
+static cz_status rw_step_wide(cz_session* s, int B, const bool gv = false) {     // gv: a handful of streams on the VALU projections (kernels_gemv.hip)
     Rwkv7Model* m = s->rwkv; const cz_rwkv7_config& c = m->cfg;
     const int C = c.hidden, F = c.d_ffn, H = C / 64, Bc = m->B;
     const int pw = pad64(c.decay_rank), pa = pad64(c.a_rank), pg = 128, pv = pad64(c.v_rank);
@@ -554,7 +554,7 @@ static cz_status rw_step_wide(cz_session* s, int B) {
         return e;
     };
     const double st_bytes = (double)B * H * 2.0 * 64 * 64 * 4;
-    const bool mid = s->rwkv_wide_mode == 1;          // 1: the K-group GEMM (32 x 32 tiles, grouped launches); 0: the tiled big-M kernel, one launch per projection
+    const bool mid = !gv && s->rwkv_wide_mode == 1;   // 1: the K-group GEMM (32 x 32 tiles, grouped launches); 0: the tiled big-M kernel, one launch per projection
     s->prof_begin(PK_RW_PREP);
     HIPCHK(cz_launch_embed(st, m->tok, m->emb, m->x, B, C));
     for (int l = 0; l < c.n_layers; ++l) {
@@ -576,6 +576,17 @@ static cz_status rw_step_wide(cz_session* s, int B) {
             const int K[7] = {C, C, C, C, C, C, C};
             s->prof_begin(PK_RW_GEMM);
             HIPCHK(cz_launch_gemm_mid_group(st, y.has_v ? 7 : 6, A, lda, W, Cc, ldc, N, K, B));
+            s->prof_end(2.0 * B * (double)C * (3 * C + pw + pa + pg + (y.has_v ? pv : 0)), 2.0 * C * (3 * C + pw + pa + pg + pv) + (double)B * C * 4 * 10);
+        } else if (gv) {   // the same seven projections, one launch of one-wave blocks (natural-layout weights)
+            const float* A[7] = {mixp(0), mixp(2), mixp(3), mixp(1), mixp(4), mixp(5), mixp(3)};
+            const int lda[7] = {C, C, C, C, C, C, C};
+            const uint16_t* W[7] = {y.r_n, y.k_n, y.v_n, y.w1_n, y.a1_n, y.g1_n, y.v1_n};
+            float* Cc[7] = {m->proj + 0, m->proj + C, m->proj + 2 * C, m->proj + ow, m->proj + oa, m->proj + og, m->proj + ov};
+            const int ldc[7] = {ldp, ldp, ldp, ldp, ldp, ldp, ldp};
+            const int N[7] = {C, C, C, pw, pa, ng, pv};
+            const int K[7] = {C, C, C, C, C, C, C};
+            s->prof_begin(PK_RW_GEMM);
+            HIPCHK(cz_launch_dec_gemv_group(st, y.has_v ? 7 : 6, A, lda, W, Cc, ldc, N, K, B));
             s->prof_end(2.0 * B * (double)C * (3 * C + pw + pa + pg + (y.has_v ? pv : 0)), 2.0 * C * (3 * C + pw + pa + pg + pv) + (double)B * C * 4 * 10);
         } else {
         HIPCHK(gemm(mixp(0), C, y.r_n, m->proj + 0, ldp, nullptr, C, C));
@@ -603,6 +614,17 @@ static cz_status rw_step_wide(cz_session* s, int B) {
             s->prof_begin(PK_RW_GEMM);
             HIPCHK(cz_launch_gemm_mid_group(st, y.has_v ? 4 : 3, A, lda, W, Cc, ldc, N, K, B));
             s->prof_end(2.0 * B * (double)C * (pw + pa + pg + (y.has_v ? pv : 0)), 2.0 * C * (pw + pa + pg + pv) + (double)B * C * 4 * 5);
+        } else if (gv) {
+            const float* A[4] = {TW, TA, TG, TV};
+            const int lda[4] = {pw, pa, pg, pv};
+            const uint16_t* W[4] = {y.w2_n, y.a2_n, y.g2_n, y.v2_n};
+            float* Cc[4] = {L2 + 0, L2 + C, L2 + 2 * C, L2 + 3 * C};
+            const int ldc[4] = {4 * C, 4 * C, 4 * C, 4 * C};
+            const int N[4] = {C, C, C, C};
+            const int K[4] = {pw, pa, ng, pv};
+            s->prof_begin(PK_RW_GEMM);
+            HIPCHK(cz_launch_dec_gemv_group(st, y.has_v ? 4 : 3, A, lda, W, Cc, ldc, N, K, B));
+            s->prof_end(2.0 * B * (double)C * (pw + pa + pg + (y.has_v ? pv : 0)), 2.0 * C * (pw + pa + pg + pv) + (double)B * C * 4 * 5);
         } else {
         HIPCHK(gemm(TW, pw, y.w2_n, L2 + 0, 4 * C, nullptr, C, pw));
         HIPCHK(gemm(TA, pa, y.a2_n, L2 + C, 4 * C, nullptr, C, pa));
@@ -617,6 +639,10 @@ static cz_status rw_step_wide(cz_session* s, int B) {
             s->prof_begin(PK_RW_GEMM);
             HIPCHK(cz_launch_gemm_mid(st, m->att, C, y.o_2, m->x, C, m->x, C, B, C, C));
             s->prof_end(2.0 * B * (double)C * C, 2.0 * C * C + (double)B * C * 12);
+        } else if (gv) {
+            s->prof_begin(PK_RW_GEMM);
+            HIPCHK(cz_launch_dec_gemv_plain(st, m->att, C, y.o_n, m->x, C, m->x, B, C, C, nullptr, 0.0f));
+            s->prof_end(2.0 * B * (double)C * C, 2.0 * C * C + (double)B * C * 12);
         } else HIPCHK(gemm(m->att, C, y.o_n, m->x, C, m->x, C, C));                        // x = x + att
         s->prof_begin(PK_RW_PREP);
         hipLaunchKernelGGL(rw_prep_ffn_kernel, dim3(B), dim3(C), shm, st, m->x, y, c.norm_eps, fxp, m->xn, m->mask, 0);
@@ -624,11 +650,16 @@ static cz_status rw_step_wide(cz_session* s, int B) {
         s->prof_end(0, (double)B * C * 4 * 4);
         s->prof_begin(PK_RW_GEMM);
         if (mid) HIPCHK(cz_launch_gemm_mid_relusq(st, m->xn, C, y.fk_2, m->ffk, F, B, F, C));
+        else if (gv) HIPCHK(cz_launch_dec_gemv_relusq(st, m->xn, C, y.fk_n, m->ffk, F, B, F, C));
         else HIPCHK(cz_launch_gemm_relusq(st, m->xn, C, y.fk_n, m->ffk, F, B, F, C));
         s->prof_end(2.0 * B * (double)C * F, 2.0 * C * F + (double)B * (C + F) * 4);
         if (mid) {
             s->prof_begin(PK_RW_GEMM);
             HIPCHK(cz_launch_gemm_mid(st, m->ffk, F, y.fv_2, m->x, C, m->x, C, B, C, F));
+            s->prof_end(2.0 * B * (double)C * F, 2.0 * C * F + (double)B * (C + F) * 4);
+        } else if (gv) {
+            s->prof_begin(PK_RW_GEMM);
+            HIPCHK(cz_launch_dec_gemv_plain(st, m->ffk, F, y.fv_n, m->x, C, m->x, B, C, F, nullptr, 0.0f));
             s->prof_end(2.0 * B * (double)C * F, 2.0 * C * F + (double)B * (C + F) * 4);
         } else HIPCHK(gemm(m->ffk, F, y.fv_n, m->x, C, m->x, C, F));                       // x = x + ffn
     }
@@ -637,12 +668,17 @@ static cz_status rw_step_wide(cz_session* s, int B) {
     HIPCHK(hipGetLastError());
     s->prof_end(0, (double)B * C * 8);
     s->prof_begin(PK_DEC_GEMM_HEAD);
-    HIPCHK(cz_launch_gemm_masked(st, m->xn, C, m->head_n, m->logits, c.vocab, B, c.vocab, C, m->mask));
+    if (gv) HIPCHK(cz_launch_dec_gemv_masked(st, m->xn, C, m->head_n, m->logits, c.vocab, B, c.vocab, C, m->mask));
+    else HIPCHK(cz_launch_gemm_masked(st, m->xn, C, m->head_n, m->logits, c.vocab, B, c.vocab, C, m->mask));
     s->prof_end(2.0 * B * (double)c.vocab * C, 2.0 * c.vocab * C + (double)B * c.vocab * 4);
     return CZ_OK;
 }
 static cz_status rw_step(cz_session* s, int B) {
     if (s->rwkv_wide_min > 0 && B >= s->rwkv_wide_min) return rw_step_wide(s, B);
+    {   // a handful of streams (one file = one stream): the wide step's natural-layout dataflow on the one-wave VALU projections
+        const cz_rwkv7_config& c = s->rwkv->cfg;
+        if (cz_dec_gemv_ok(B, c.hidden, false) && cz_dec_gemv_ok(B, c.d_ffn, false) && c.hidden <= 768 && c.d_ffn % 64 == 0) return rw_step_wide(s, B, true);
+    }
     return rw_step_narrow(s, B);
 }
 

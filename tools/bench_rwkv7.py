@@ -12,6 +12,8 @@ cfg = cz.rwkv7_0b1_config()
 LANE = int(sys.argv[3]) if len(sys.argv) > 3 else B
 s = cz.Session("rwkv7", cfg, seed=0x5EED, embed_std=0.02, max_streams=min(B, LANE))
 s.debug_set("max_lanes", int(sys.argv[4]) if len(sys.argv) > 4 else 4)
+for kv in filter(None, os.environ.get("CZ_BENCH_DEBUG_SET", "").split(",")):       # e.g. CZ_BENCH_DEBUG_SET=gemv_max_rows=0
+    k, v = kv.split("="); s.debug_set(k, int(v))
 rng = np.random.default_rng(1)
 streams = [np.concatenate([[0], rng.integers(0, cfg.vocab, T)]).astype(np.uint32) for _ in range(B)]
 for rep in range(2):                       # first pass warms up
@@ -25,4 +27,4 @@ assert all(np.array_equal(a, b) for a, b in zip(streams, outs))
 n = B * T
 print(json.dumps({"backend": "rwkv7", "shape": "RWKV7-0.1B (V65536 C768 L12)", "streams": B, "tokens_per_stream": T,
                   "compress_tokens_per_s": round(n / (t1 - t0), 1), "decompress_tokens_per_s": round(n / (t2 - t1), 1),
-                  "self_test_tokens_per_s": round(n / (t2 - t0), 1), "bits_per_token_synthetic": round(8 * sum(len(p) for p in pays) / n, 3)}))
+                  "self_test_tokens_per_s": round(n / (t2 - t0), 1), "debug_set": os.environ.get("CZ_BENCH_DEBUG_SET", ""), "bits_per_token_synthetic": round(8 * sum(len(p) for p in pays) / n, 3)}))
