@@ -251,9 +251,12 @@ __global__ __launch_bounds__(64) void dec_gemv_group_kernel(gemv_group g) {
 }
 
 int g_gemv_fold_attn = 1;       // tuning knob (cz_debug_set "gemv_fold_attn"): 1 = the o-projection adds up the split attention's chunk partials itself (no da_split_sum_kernel launch)
-int g_gemv_max_rows = 4;         // tuning knob (cz_debug_set "gemv_max_rows"): groups of at most this many streams take the VALU projections (0 = never)
+// tuning knob (cz_debug_set "gemv_max_rows"): groups of at most this many streams take the VALU projections (0 = never).  Measured at 767 keys, ms per step, MFMA
+// projections (dec_gemm_kernel) against these (profiles/r04_single_stream/): 1 stream 1.376 / 0.921, 2: 1.42 / 1.04, 4: 1.47 / 1.29, 8: 1.52 / 1.40,
+// 12: 1.67 / 1.52, 16: 1.81 / 1.69, 32: 1.79 / 1.95, 64: 2.08 / 2.63 — rows beyond four are further blocks (blockIdx.y) that re-read the weights from L2
+int g_gemv_max_rows = 16;
 bool cz_dec_gemv_ok(int M, int K, bool norm) {
-    if (g_gemv_max_rows <= 0 || M > g_gemv_max_rows || M > 4 || K % 64 || K > 3072) return false;
+    if (g_gemv_max_rows <= 0 || M > g_gemv_max_rows || K % 64 || K > 3072) return false;      // (more than four rows: row groups of four, blockIdx.y)
     return !norm || 4 * (K >> 6) <= 64;
 }
 template <int EPI, bool NORM, int MB, int CPL, int ASUM = 0, int XRP = 0>

@@ -677,7 +677,8 @@ static cz_status rw_step(cz_session* s, int B) {
     if (s->rwkv_wide_min > 0 && B >= s->rwkv_wide_min) return rw_step_wide(s, B);
     {   // a handful of streams (one file = one stream): the wide step's natural-layout dataflow on the one-wave VALU projections
         const cz_rwkv7_config& c = s->rwkv->cfg;
-        if (cz_dec_gemv_ok(B, c.hidden, false) && cz_dec_gemv_ok(B, c.d_ffn, false) && c.hidden <= 768 && c.d_ffn % 64 == 0) return rw_step_wide(s, B, true);
+        // (up to four streams here: at the 0.1B shape — K = 768 and 3072 — eight tie with dec_gemm_kernel, sixteen lose 18 %: profiles/r04_single_stream/)
+        if (B <= 4 && cz_dec_gemv_ok(B, c.hidden, false) && cz_dec_gemv_ok(B, c.d_ffn, false) && c.hidden <= 768 && c.d_ffn % 64 == 0) return rw_step_wide(s, B, true);
     }
     return rw_step_narrow(s, B);
 }

@@ -1508,7 +1508,10 @@ extern "C" cz_status cz_debug_decode_steps(cz_session* s, int B, int pos, int it
     if (use_graph && !s->dbg_ge) { cz_set_error("cz_debug_decode_steps: prepare first (iters <= 0)"); return CZ_ERR_STATE; }
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, s->stream));
-    for (int i = 0; i < iters; ++i) { if (use_graph) HIPCHK(hipGraphLaunch(s->dbg_ge, s->stream)); else CZCHK(one()); }
+    for (int i = 0; i < iters; ++i) {
+        if (use_graph) HIPCHK(hipGraphLaunch(s->dbg_ge, s->stream)); else CZCHK(one());
+        if (s->step_sync) HIPCHK(hipStreamSynchronize(s->stream));      // (profiler runs: one doorbell per packet, never a backlog — DESIGN.md §9)
+    }
     HIPCHK(hipEventRecord(e1, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));

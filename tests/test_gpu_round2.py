@@ -187,7 +187,7 @@ def test_wide_group_step_is_bitexact(cz, czo, shape, path):
         gcfg, ocfg, V, n_tok, seed = cz.smollm2_135m_config(), czo.smollm2_135m_config(), 49152, 40, 0x5EED
     g = cz.Session("smollm", gcfg, seed=seed, embed_std=0.05 if shape == "tiny" else 0.02, max_streams=6)
     o = czo.SmolLmSession(ocfg, seed=seed, embed_std=0.05 if shape == "tiny" else 0.02)
-    g.debug_set("gemv_max_rows", 4 if path == "gemv" else 0)
+    g.debug_set("gemv_max_rows", 16 if path == "gemv" else 0)                 # ("gemv": the shipped value — the five-stream decode below runs as row groups of 4 + 1)
     g.debug_set("dec_attn_split_max", 0 if path in ("tiled", "np2", "hybrid", "mid8") else 128)   # small groups: the one-kernel forms below (0) / the three-launch split form (round 3)
     g.debug_set("dec_attn_small_grid", 0 if path in ("tiled", "np2") else 128)   # decode attention with 8 waves per block (whole-device grids) / 16 (small grids)
     g.debug_set("dec_attn_split_heads", 0 if path == "hybrid" else 1)            # small grids: a block per kv head (0) / per query head (1, the default)

@@ -15,6 +15,7 @@ import candlezip_amd as cz
 
 
 WM = [256, 1]
+STEP_SYNC = [0]
 
 
 def run_config(parent, cfgs, name, B, L, pos, x, av, fn, g, prof, iters, sym, av1=-1, pr0=0, pr1=0):
@@ -31,6 +32,7 @@ def run_config(parent, cfgs, name, B, L, pos, x, av, fn, g, prof, iters, sym, av
         if (pr1 if k & 1 else pr0):
             s.debug_set("stream_priority", pr1 if k & 1 else pr0)           # -1 = high, 1 = low
         s.debug_set("fuse_norm", fn)
+        s.debug_set("step_sync", STEP_SYNC[0])
         s.debug_set("wide_min_streams", WM[0]); s.debug_set("wide_mode", WM[1])
     ms = [0.0] * L; err = []
     gate = threading.Barrier(L)
@@ -77,12 +79,13 @@ def main():
     parent = cz.Session("smollm", cz.smollm2_135m_config(), seed=0x5EED, embed_std=0.02, max_streams=args.max_streams)
     for c in args.configs:
         name, _, kv = c.partition(":")
-        d = dict(B=128, L=1, pos=767, x=0, av=0, fn=0, g=1, prof=0, gt=384, mt=8, wm=256, dw=256, wmode=1, nw=4, pad=0, mq=1, sp=36, av1=-1, pr0=0, pr1=0, gv=4, fa=1)
+        d = dict(B=128, L=1, pos=767, x=0, av=0, fn=0, g=1, prof=0, gt=384, mt=8, wm=256, dw=256, wmode=1, nw=4, pad=0, mq=1, sp=36, av1=-1, pr0=0, pr1=0, gv=4, fa=1, ss=0)
         for item in kv.split(","):
             if item:
                 k, v = item.split("=")
                 d[k] = int(v)
         parent.debug_set("dec_grid_target", d["gt"]); parent.debug_set("dec_mt_max", d["mt"])     # (process-wide knobs)
+        STEP_SYNC[0] = d["ss"]                                                # ss=1: one host wait per step (eager runs under rocprofv3)
         WM[0] = d["wm"]; WM[1] = d["wmode"]; parent.debug_set("dec_wide_rows", d["dw"]); parent.debug_set("mid_nw", d["nw"]); parent.debug_set("dec_attn_lds_pad", d["pad"])
         parent.debug_set("gemv_max_rows", d["gv"]); parent.debug_set("gemv_fold_attn", d["fa"])      # fa: the o-projection adds up the split attention's partials
         parent.debug_set("mid_quad", d["mq"]); parent.debug_set("dec_attn_split_max", d["sp"])     # mq: gemm_mid blocks share sum + epilogue over their waves; sp: split attention up to this many (stream, head) pairs
