@@ -17,7 +17,8 @@ verified when its last window has been decoded.  Pipeline fill (two windows of c
 
 Contract line (rank 0): metric/value/unit/n_gpus/steps/warmup/ms_per_step/... + "roofline" (the kernel FUNCTION with the largest
 total time, all its instantiations summed; HIP-event timed on the library's stream in an eager pass inside this script) +
-"roofline_dec_attention", "roofline_mfma_gemm" + "cpu_baseline" (oracle, reference schedule, bounded sample, rank 0 at N=1 only).
+"roofline_dec_attention", "roofline_mfma_gemm" + "cpu_baseline" (oracle, reference schedule, bounded sample, rank 0 at N=1 only) +
+"single_stream" (rank 0 at N=1: ONE stream alone on the device, as the reference CLI runs a file — an untimed extra, never part of `value`).
 """
 import argparse
 import json
@@ -272,6 +273,28 @@ def profile_pass(cz, sess, streams, context, reprime, skip):
     return prof
 
 
+def single_stream_line(cz, cfg, tokens, context, reprime):
+    """BASELINE configs[1] as the reference CLI runs it: ONE stream (one file) alone on the device, compress then decompress, round trip checked.  A short
+    stream on a session of its own, untimed part of the run: the figure beside the many-stream `value` (narrow groups on VALU projections)."""
+    s1 = cz.Session("smollm", cfg, seed=0x5EED, embed_std=0.02, max_streams=1)
+    try:
+        rng = np.random.default_rng(4)
+        ids = np.concatenate([[0], rng.integers(0, cfg.vocab, tokens)]).astype(np.uint32)
+        s1.encode_tokens(ids[:600], context, reprime)                    # page the code in
+        t0 = time.perf_counter()
+        lo, hi = s1.encode_tokens(ids, context, reprime)
+        pay, zw = cz.ac_encode_pairs(lo, hi)
+        t1 = time.perf_counter()
+        out = s1.decode_tokens(pay, tokens, context, reprime)
+        t2 = time.perf_counter()
+        ok = bool(zw or np.array_equal(out, ids))
+    finally:
+        s1.close()
+    return {"workload": f"ONE stream x {tokens} tokens (one file = one stream, as the reference CLI runs it), context {context}, reprime_interval {reprime}",
+            "compress_tokens_per_s": round(tokens / (t1 - t0), 1), "decompress_tokens_per_s": round(tokens / (t2 - t1), 1),
+            "self_test_tokens_per_s": round(tokens / (t2 - t0), 1), "round_trip_exact": ok, "zero_width_steps": int(zw)}
+
+
 def cpu_baseline(sample_tokens, context, reprime):
     """the oracle (CPU restatement of the reference path) in the REFERENCE's schedule: one M=1 forward per token, a
     511-token batched re-prime every `reprime` tokens, host softmax->CDF->coder per token.  Bounded sample."""
@@ -516,6 +539,7 @@ def main():
     ap.add_argument("--context", type=int, default=512)
     ap.add_argument("--reprime-interval", type=int, default=512)
     ap.add_argument("--cpu-sample", type=int, default=640, help="tokens of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--single-stream-tokens", type=int, default=2560, help="tokens of the untimed single-stream measurement reported as `single_stream` (smollm line, one rank; 0 = skip)")
     ap.add_argument("--dec-priority", type=int, default=0, help="HIP stream priority of the decode lanes: -1 = high, 0 = normal")
     ap.add_argument("--enc-priority", type=int, default=0, help="HIP stream priority of the forked compress session (--overlap 1): 1 = low, 0 = normal, -1 = high")
     ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE", help="library tuning knob (cz_debug_set)")
@@ -717,6 +741,9 @@ def main():
                     line["roofline_mfma_gemm"]["timed_region"] = {
                         "achieved": round(t["flops"] / (t["total_ms"] * 1e-3) / 1e12, 3), "unit": "TFLOP/s", "launches": t["launches"],
                         "note": "HIP events on decode lane 0 over the timed region: its re-prime launches, with the other lane and the encoder sharing the device"}
+        if world == 1 and args.single_stream_tokens > 0 and not args.tiny:
+            line["single_stream"] = single_stream_line(cz, cfg, args.single_stream_tokens, args.context, args.reprime_interval)
+            note(f"single stream: {line['single_stream']['decompress_tokens_per_s']} tokens/s decompress")
         if world == 1 and args.cpu_sample > 0 and not args.tiny:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.context, args.reprime_interval)
         print(json.dumps(line), flush=True)

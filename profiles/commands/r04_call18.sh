@@ -1,0 +1,16 @@
+#!/bin/bash
+# round-4 GPU call 18: this round's rocprofv3 evidence of the profile passes (tools/profile_pass.py: eager, one host wait per token — the safe profiled form):
+# kernel trace + FETCH_SIZE / WRITE_SIZE passes of the SmolLM pass, kernel trace of the RWKV7 pass
+set -o pipefail
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4c18; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+run() { local name=$1; shift; timeout -k 10 900 rocprofv3 "$@" > $O/$name.out 2> $O/$name.err; local rc=$?; echo "$name rc=$rc"; grep "profile_pass\]" $O/$name.err | tail -1; return $rc; }
+run kt_smollm --kernel-trace --output-format csv -d $O/kt_smollm -- python3 $R/tools/profile_pass.py smollm || exit 1
+python3 $R/tools/prof_summary.py $O/kt_smollm $O/r04_pass2048_s512 --skip-frac 0.25; rm -rf $O/kt_smollm; head -12 $O/r04_pass2048_s512_kernel_stats.csv
+run pmc_f_smollm --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f_smollm -- python3 $R/tools/profile_pass.py smollm --tokens 1024 || exit 1
+python3 $R/tools/prof_summary.py $O/pmc_f_smollm $O/r04_pmc1024_FETCH_SIZE --skip-frac 0.5; rm -rf $O/pmc_f_smollm
+run pmc_w_smollm --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w_smollm -- python3 $R/tools/profile_pass.py smollm --tokens 1024 || exit 1
+python3 $R/tools/prof_summary.py $O/pmc_w_smollm $O/r04_pmc1024_WRITE_SIZE --skip-frac 0.5; rm -rf $O/pmc_w_smollm
+run kt_rwkv7 --kernel-trace --output-format csv -d $O/kt_rwkv7 -- python3 $R/tools/profile_pass.py rwkv7 || exit 1
+python3 $R/tools/prof_summary.py $O/kt_rwkv7 $O/r04_passrwkv7_s1024_t256 --skip-frac 0.0001; rm -rf $O/kt_rwkv7; head -8 $O/r04_passrwkv7_s1024_t256_kernel_stats.csv
+ls $O

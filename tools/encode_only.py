@@ -24,6 +24,8 @@ dt = time.perf_counter() - t0
 prof = s.profile_read()
 print(json.dumps({"streams": B, "tokens": T, "compress_tokens_per_s": round(reps * B * T / dt, 1),
                   "families_ms": {k: round(v["total_ms"], 1) for k, v in prof.items()},
+                  "families_tflops": {k: round(v["flops"] / max(v["total_ms"], 1e-9) / 1e9, 1) for k, v in prof.items() if v["flops"] > 0},
+                  "families_launches": {k: v["launches"] for k, v in prof.items()},
                   "gemm_tflops": round(sum(v["flops"] for k, v in prof.items() if k.startswith("gemm")) / max(sum(v["total_ms"] for k, v in prof.items() if k.startswith("gemm")), 1e-9) / 1e9, 1),
                   "attention_tflops": round(prof.get("attention_f32_mfma", {"flops": 0})["flops"] / max(prof.get("attention_f32_mfma", {"total_ms": 1e-9})["total_ms"], 1e-9) / 1e9, 1)}))
 s.close()
