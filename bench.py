@@ -273,10 +273,10 @@ def profile_pass(cz, sess, streams, context, reprime, skip):
     return prof
 
 
-def single_stream_line(cz, cfg, tokens, context, reprime):
+def single_stream_line(cz, cfg, tokens, context, reprime, backend="smollm"):
     """BASELINE configs[1] as the reference CLI runs it: ONE stream (one file) alone on the device, compress then decompress, round trip checked.  A short
     stream on a session of its own, untimed part of the run: the figure beside the many-stream `value` (narrow groups on VALU projections)."""
-    s1 = cz.Session("smollm", cfg, seed=0x5EED, embed_std=0.02, max_streams=1)
+    s1 = cz.Session(backend, cfg, seed=0x5EED, embed_std=0.02, max_streams=1)
     try:
         rng = np.random.default_rng(4)
         ids = np.concatenate([[0], rng.integers(0, cfg.vocab, tokens)]).astype(np.uint32)
@@ -290,7 +290,7 @@ def single_stream_line(cz, cfg, tokens, context, reprime):
         ok = bool(zw or np.array_equal(out, ids))
     finally:
         s1.close()
-    return {"workload": f"ONE stream x {tokens} tokens (one file = one stream, as the reference CLI runs it), context {context}, reprime_interval {reprime}",
+    return {"workload": f"ONE stream x {tokens} tokens (one file = one stream, as the reference CLI runs it)" + (f", context {context}, reprime_interval {reprime}" if backend == "smollm" else ", recurrent state (no re-prime)"),
             "compress_tokens_per_s": round(tokens / (t1 - t0), 1), "decompress_tokens_per_s": round(tokens / (t2 - t1), 1),
             "self_test_tokens_per_s": round(tokens / (t2 - t0), 1), "round_trip_exact": ok, "zero_width_steps": int(zw)}
 
@@ -509,6 +509,8 @@ def main_rwkv7(args):
             "roofline_mfma_gemm": roof("gemm_bf16w_f32_mfma", "mfma", "gemm_bf16w_kernel<128, 128", "gemm_bf16w_kernel (encode projections, lm_head)"),
             "families_ms_profile_pass": {k: round(v["total_ms"], 2) for k, v in prof.items()},
         }
+        if world == 1 and args.single_stream_tokens > 0 and not args.tiny:
+            line["single_stream"] = single_stream_line(cz, cfg, min(args.single_stream_tokens, 2048), 512, 512, "rwkv7")
         if world == 1 and args.cpu_sample > 0 and not args.tiny:
             line["cpu_baseline"] = cpu_baseline_rwkv7(min(args.cpu_sample, 400))
         print(json.dumps(line), flush=True)
