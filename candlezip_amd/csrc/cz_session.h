@@ -66,7 +66,7 @@ struct cz_session {
     // packed-row work buffers
     DevBuf tok, x, xn, qkv, gu, h, seqd, roped, rowidx, sym, clo, chi, xl, logits, payload, outids, decst, seqd_q, xc, rc;   // seqd_q, xc, rc: llama_body's last layer on the wanted rows only
     size_t max_batch_rows = 98304, logit_batch_rows = 8192;
-    int force_big_gemm = 0, serial_cdf = 0, decode_v1 = 0, no_graph = 0, fuse_norm = 0, step_sync = 0, dbg_skip = 0, wide_min_streams = 256, wide_mode = 3;
+    int force_big_gemm = 0, serial_cdf = 0, decode_v1 = 0, no_graph = 0, fuse_norm = 0, step_sync = 0, dbg_skip = 0, wide_min_streams = 144, wide_mode = 3;     // (wide_min_streams: 144 streams 2.90 ms per step on the wide form against 3.27 on the narrow one, 160: 3.00 / 3.40, 128: 2.78 / 2.62 — profiles/r04_single_stream/steps_b20_to_b256_step_forms.jsonl)
     hipGraph_t dbg_g = nullptr; hipGraphExec_t dbg_ge = nullptr;      // cz_debug_decode_steps
     int rwkv_wide_mode = 1;             // rw_step_wide's projections: 1 = gemm_mid_kernel (grouped launches), 0 = the tiled big-M kernel
     int rwkv_wide_min = 256;            // RWKV7 lock-step groups of at least this many streams take the tiled-GEMM step (rw_step_wide); 0 = never
