@@ -69,7 +69,8 @@ struct cz_session {
     int force_big_gemm = 0, serial_cdf = 0, decode_v1 = 0, no_graph = 0, fuse_norm = 0, step_sync = 0, dbg_skip = 0, wide_min_streams = 144, wide_mode = 3;     // (wide_min_streams: 144 streams 2.90 ms per step on the wide form against 3.27 on the narrow one, 160: 3.00 / 3.40, 128: 2.78 / 2.62 — profiles/r04_single_stream/steps_b20_to_b256_step_forms.jsonl)
     hipGraph_t dbg_g = nullptr; hipGraphExec_t dbg_ge = nullptr;      // cz_debug_decode_steps
     int rwkv_wide_mode = 1;             // rw_step_wide's projections: 1 = gemm_mid_kernel (grouped launches), 0 = the tiled big-M kernel
-    int rwkv_wide_min = 256;            // RWKV7 lock-step groups of at least this many streams take the tiled-GEMM step (rw_step_wide); 0 = never
+    int rwkv_wide_min = 80;             // RWKV7 lock-step groups of at least this many streams take the wide step (rw_step_wide: grouped gemm_mid launches); 0 = never.  Round 4, decompress
+                                        // tokens/s narrow / wide: 64 streams 52.1 k / 50.1 k, 96: 66.2 k / 69.9 k, 128: 84.2 k / 88.5 k, 160: 85.8 k / 101.3 k, 192: 86.9 k / 114.7 k (profiles/r04_single_stream/)
     int rwkv_seq = 1;                   // 1 = RWKV7 encode is sequence-parallel (rw_encode_seq_group); 0 = the lock-step token-by-token walk (cz_rwkv7_encode_group)
     int no_last_prune = 0;              // test knob: 1 = the last layer's tail on every row (llama_body)
     int stream_prio = 0;                // HIP priority of this session's stream and of the decode lanes it makes (cz_debug_set "stream_priority")
