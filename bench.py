@@ -407,20 +407,49 @@ def main_rwkv7(args):
         return [np.concatenate([[0], rng.integers(0, cfg.vocab, T)]).astype(np.uint32) for _ in range(S)]
 
     te = td = 0.0; nbytes = 0
+    # --overlap 1 (default): a two-stage pipeline as on the smollm line — the compress of batch k + 1 runs on a forked session (own HIP stream and work buffers,
+    # shared weights) WHILE batch k is decompressed: the MFMA-bound sequence-parallel encode beside the lock-step decode.  Every batch is both compressed and
+    # decompressed; K steps are K compress halves and K decompress halves (the first batch's compress is the untimed pipeline fill, the last step's is of a batch
+    # whose decompress would be step K + 1).  --overlap 0: one after the other, each half timed alone.
+    enc_sess = sess.fork() if args.overlap else None
+    import threading
 
-    def one(step):
-        nonlocal te, td, nbytes
+    def compress(se, step):
         streams = batch(step)
         t0 = time.perf_counter()
-        pairs = sess.encode_tokens_batch(streams)
+        pairs = se.encode_tokens_batch(streams)
         pays = [cz.ac_encode_pairs(lo, hi)[0] for lo, hi in pairs]
-        t1 = time.perf_counter()
+        return streams, pays, time.perf_counter() - t0
+
+    def decompress(streams, pays):
+        t0 = time.perf_counter()
         outs = sess.decode_tokens_batch(pays, [T] * S)
-        t2 = time.perf_counter()
+        dt = time.perf_counter() - t0
         for a, b in zip(streams, outs):
             if not np.array_equal(a, b):
                 raise RuntimeError("self-test round trip mismatch")
-        te += t1 - t0; td += t2 - t1; nbytes += sum(len(p) for p in pays)
+        return dt
+
+    pending = [None]
+
+    def one(step):
+        nonlocal te, td, nbytes
+        if enc_sess is None:
+            streams, pays, dte = compress(sess, step)
+            dtd = decompress(streams, pays)
+        else:
+            if pending[0] is None:
+                pending[0] = compress(enc_sess, step)                        # pipeline fill (warmup / untimed)
+            streams, pays, _ = pending[0]
+            box = {}
+            th = threading.Thread(target=lambda: box.update(r=compress(enc_sess, step + 1)))
+            th.start()
+            dtd = decompress(streams, pays)
+            th.join()
+            if "r" not in box:
+                raise RuntimeError("the compress half failed")
+            pending[0] = box["r"]; dte = box["r"][2]
+        te += dte; td += dtd; nbytes += sum(len(p) for p in pays)
 
     def barrier():
         sess.synchronize()
@@ -429,8 +458,8 @@ def main_rwkv7(args):
             sess.synchronize()
 
     sess.profile_enable(False)
-    for w in range(args.warmup):
-        one(-1 - w)
+    for w in range(max(args.warmup, 1 if enc_sess is not None else 0)):      # (the pipeline needs one untimed step to fill)
+        one(-100 + w)
     te = td = 0.0; nbytes = 0
     barrier()
     t0 = time.perf_counter()
@@ -498,8 +527,8 @@ def main_rwkv7(args):
             "value": round(total_tok / elapsed, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"--backend rwkv7, Canterbury-sized inputs as 64 KiB chunks: {S} streams x {T} tokens per GPU and step, one step = compress "
-                                   f"(sequence-parallel) + coder + decompress (lock-step) of a fresh batch, RWKV7-0.1B shape ({'tiny test model' if args.tiny else 'C768 L12 H12x64 ffn3072 V65536 (+256 literals)'}), seeded synthetic weights",
-                       "streams_per_gpu": S, "decode_lanes": groups, "streams_per_lane": per_lane, "tokens_per_stream": T, "parallelism": f"files x{world} (no data-path collective)"},
+                                   f"(sequence-parallel) + coder + decompress (lock-step) of a fresh batch{' — the compress of batch k + 1 on a forked session beside the decompress of batch k' if args.overlap else ''}, RWKV7-0.1B shape ({'tiny test model' if args.tiny else 'C768 L12 H12x64 ffn3072 V65536 (+256 literals)'}), seeded synthetic weights",
+                       "streams_per_gpu": S, "decode_lanes": groups, "streams_per_lane": per_lane, "tokens_per_stream": T, "compress_beside_decompress": bool(args.overlap), "parallelism": f"files x{world} (no data-path collective)"},
             "bits_per_byte": None, "bits_per_token_synthetic": round(8.0 * nbytes / max(tok, 1), 3),
             "steps_verified": args.steps, "ranks_seen": (dist.get_world_size() if dist is not None else 1),
             "compress_tokens_per_s_rank0": round(tok / te, 1) if te else None, "decompress_tokens_per_s_rank0": round(tok / td, 1) if td else None,
@@ -514,6 +543,8 @@ def main_rwkv7(args):
         if world == 1 and args.cpu_sample > 0 and not args.tiny:
             line["cpu_baseline"] = cpu_baseline_rwkv7(min(args.cpu_sample, 400))
         print(json.dumps(line), flush=True)
+    if enc_sess is not None:
+        enc_sess.close()
     sess.close()
     if dist is not None:
         dist.barrier()
