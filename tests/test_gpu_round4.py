@@ -130,3 +130,35 @@ def test_rwkv7_narrow_groups_valu_projections_are_bitexact(cz, czo, shape, gemv)
             for s_, out in zip(streams[:nb], g.decode_tokens_batch(pays[:nb], lens[:nb])):
                 assert np.array_equal(out, s_), (nb, no_graph)
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("backend,n_streams", [("smollm", 150), ("rwkv7", 84)])
+def test_groups_at_the_wide_step_thresholds_round_trip(cz, czo, backend, n_streams):
+    """round 4 moved the wide decode step down to groups of 144 (SmolLM) / 80 (RWKV7) streams: ONE group just past the threshold — a row count that is no
+    multiple of the 32-row tiles — with the shipped knobs, at the BASELINE shapes: stream 0 against the oracle, every stream's round trip, and the same
+    payloads decoded in groups of 12 (the narrow forms) give the same ids"""
+    if backend == "smollm":
+        gcfg, ocfg, V, n_tok, seed, std = cz.smollm2_135m_config(), czo.smollm2_135m_config(), 49152, 14, 0x5EED, 0.02
+        o = czo.SmolLmSession(ocfg, seed=seed, embed_std=std)
+    else:
+        gcfg, ocfg, V, n_tok, seed, std = cz.rwkv7_0b1_config(), czo.rwkv7_0b1_config(), 65536, 8, 3, 0.02
+        o = czo.Rwkv7Session(ocfg, seed=seed, embed_std=std)
+    g = cz.Session(backend, gcfg, seed=seed, embed_std=std, max_streams=n_streams)
+    rng = np.random.default_rng(77)
+    lens = [n_tok - (k % 3) for k in range(n_streams)]
+    streams = [np.concatenate([[0], rng.integers(0, V, n)]).astype(np.uint32) for n in lens]
+    pairs = g.encode_tokens_batch(streams)
+    coded = [cz.ac_encode_pairs(lo, hi) for lo, hi in pairs]
+    ref_p = o.encode_tokens(streams[0])[0]
+    assert coded[0][0] == ref_p
+    outs = g.decode_tokens_batch([p for p, _ in coded], lens)                  # one group of n_streams: the wide step
+    for s_, out, (_, z) in zip(streams, outs, coded):
+        if z == 0:
+            assert np.array_equal(out, s_)
+    g.close()
+    g2 = cz.Session(backend, gcfg, seed=seed, embed_std=std, max_streams=12)   # groups of 12 on lanes: the narrow forms
+    g2.debug_set("max_lanes", 2)
+    outs2 = g2.decode_tokens_batch([p for p, _ in coded[:36]], lens[:36])
+    for a, b in zip(outs[:36], outs2):
+        assert np.array_equal(a, b)
+    g2.close(); o.close()
