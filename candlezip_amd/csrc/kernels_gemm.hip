@@ -29,6 +29,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 // EPI = 1 (gate|up projection of the MLP): W holds the gate and up rows interleaved in groups of 32 (cz_launch_gu_interleave), so the two
 // 32-column MFMA tiles of a wave are the gate and the up values of the SAME 32 hidden columns and the epilogue writes
 // silu(gate) * up straight into H [M][N/2] — the 2 x f wide intermediate never exists in HBM.
+// tuning build (make gemm_clock, tools/gemm_clock.py): thread 0 of every 64th block accumulates shader-clock ticks (s_memtime) and 100 MHz ticks (s_memrealtime) over its
+// K loop: their ratio is the clock the chip holds under this kernel's load (MI355X_MICROARCH "DVFS give-back" item 6) — the f32 MFMA peak AT THAT CLOCK is what the
+// kernel can be priced against.  The stamps go to a buffer of their own; no output depends on them.
+#ifdef CZ_GEMM_CLOCK
+__device__ unsigned long long g_gemm_clock[32];      // [0] shader ticks in K loops, [1] 100 MHz ticks in K loops, [2] sampled blocks, [3] their K tiles, [4] shader ticks entry -> K loop (first tile staged), [5] K loop end -> stores issued; [8..13] the same for the BN = 64 tiles
+extern "C" void cz_debug_gemm_clock(unsigned long long* out8, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gemm_clock), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_clock), z, sizeof z); }
+}
+#endif
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restrict__ A, int lda,
                                                          const uint16_t* __restrict__ W, float* __restrict__ C, int ldc,
@@ -42,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restr
 
     const int sid = xcd_remap(blockIdx.x, nblocks);
     const int bm = sid / nbx, bn = sid % nbx;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (the wave index in an SGPR: everything derived from it stays scalar)
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
 
@@ -50,21 +61,29 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restr
     uint4 rb[PB];
     const int srow = tid >> 3, sg = tid & 7;      // staging: row within a 32-row pass, 8-wide k group
 
+    // Addresses as buffer descriptor (block-uniform tile origin, SGPRs) + per-lane 32-bit byte offset computed ONCE + scalar offset: the loads of the K loop and
+    // the stores of the epilogue then cost no vector instruction besides themselves (`buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen`).  A co-resident
+    // block's MFMA stream leaves this wave about two vector issues per 64-cycle MFMA (round 4, profiles/r04_gemm_phases/): every address VALU in the prologue,
+    // the loop and the epilogue is paid ~30 cycles apiece, and the 64-bit address arithmetic of plain pointers was most of the epilogue's 47 k cycles.
+    // Rows past M re-read row M - 1: their results are never stored.
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (size_t)(bm * BM) * lda), 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(W + (size_t)(bn * BN) * K), 0, 0xffffffffu, 0x00020000);
+    const int mrem = M - 1 - bm * BM;             // last valid row of this tile (>= 0)
+    unsigned aoff[PA];                            // byte offsets inside the tile's rows
+#pragma unroll
+    for (int p = 0; p < PA; ++p) aoff[p] = ((unsigned)min(p * 32 + srow, mrem) * (unsigned)lda + sg * 8) * 4u;
+    const unsigned woff = ((unsigned)srow * (unsigned)K + sg * 8) * 2u;
+
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
-            int row = bm * BM + p * 32 + srow;
-            if (row < M) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(A + (size_t)row * lda + kt * 64 + sg * 8);
-                ra[p][0] = src[0]; ra[p][1] = src[1];
-            } else {
-                ra[p][0] = f32x4{0, 0, 0, 0}; ra[p][1] = f32x4{0, 0, 0, 0};
-            }
+            ra[p][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff[p], kt * 256, 0));
+            ra[p][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff[p], kt * 256 + 16, 0));
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-            int n = bn * BN + p * 32 + srow;
-            rb[p] = *reinterpret_cast<const uint4*>(W + (size_t)n * K + kt * 64 + sg * 8);
+            const auto w = __builtin_amdgcn_raw_buffer_load_b128(rsW, woff, (p * 32 * K + kt * 64) * 2, 0);
+            rb[p] = uint4{w[0], w[1], w[2], w[3]};
         }
     };
     // LDS image: within every group of 8 k-values the even k come first, then the odd k, so that the b128 read of
@@ -89,9 +108,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restr
 
     f32x16 tot[TM][TN];
     const int nk = K / 64;
+#ifdef CZ_GEMM_CLOCK
+    const bool clk = tid == 0 && (blockIdx.x & 63) == 0;
+    unsigned long long ckin = 0, ck0 = 0, rt0 = 0;
+    constexpr int CKO = 8 * ((BN == 64 ? 1 : 0) + (EPI == 1 ? 2 : 0));      // [0] BN 128 plain (lm_head), [8] BN 64 (q|k|v, o, down), [16] BN 128 SwiGLU (gate|up)
+    if (clk) ckin = __builtin_amdgcn_s_memtime();
+#endif
     load_tile(0);
     store_tile();
     __syncthreads();
+#ifdef CZ_GEMM_CLOCK
+    if (clk) { ck0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) load_tile(kt + 1);            // global loads in flight under the MFMA chain
         f32x16 acc[TM][TN];
@@ -130,43 +158,107 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restr
         __syncthreads();                                // every wave is done reading this K tile
         if (kt + 1 < nk) { store_tile(); __syncthreads(); }
     }
+#ifdef CZ_GEMM_CLOCK
+    unsigned long long ck1 = 0;
+    if (clk) {
+        ck1 = __builtin_amdgcn_s_memtime(); const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&g_gemm_clock[CKO + 0], ck1 - ck0); atomicAdd(&g_gemm_clock[CKO + 1], rt1 - rt0); atomicAdd(&g_gemm_clock[CKO + 2], 1ull);
+        atomicAdd(&g_gemm_clock[CKO + 3], (unsigned long long)nk); atomicAdd(&g_gemm_clock[CKO + 4], ck0 - ckin);
+    }
+#define CZ_TAIL_STAMP() do { if (clk) atomicAdd(&g_gemm_clock[CKO + 5], (unsigned long long)__builtin_amdgcn_s_memtime() - ck1); } while (0)
+#else
+#define CZ_TAIL_STAMP() do { } while (0)
+#endif
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int row0 = bm * BM + wm * TM * 32, col0 = bn * BN + wn * TN * 32;      // block- and wave-uniform
+    const bool full = bm * BM + BM <= M && !row_mask;                            // every row of the tile is stored: no per-row predicate
+    // full tiles: one vector instruction per store / residual load (descriptor at the tile's origin, the lane's fixed byte offset, a scalar offset per row)
+    const int wrow = wm * TM * 32, wcol = wn * TN * 32;                          // this wave's corner inside the tile (scalar)
     if (EPI == 1) {
         static_assert(EPI != 1 || TN == 2, "the SwiGLU epilogue pairs the two column tiles of a wave");
+        if (full) {
+            const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C + (size_t)(bm * BM) * ldc + bn * BN / 2, 0, 0xffffffffu, 0x00020000);
+            const unsigned loff = ((unsigned)(4 * lh) * (unsigned)ldc + lr) * 4u;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = cz_siluf(tot[i][0][r]) * tot[i][TN - 1][r];  // silu(gate) * up (llama.rs MLP)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, loff, ((wrow + i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + wcol / 2) * 4, 0);
+                }
+            CZ_TAIL_STAMP();
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int hcol = (bn * BN + wn * TN * 32) / 2 + lr;
+            const int hcol = col0 / 2 + lr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = bm * BM + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < M) C[(size_t)row * ldc + hcol] = cz_siluf(tot[i][0][r]) * tot[i][TN - 1][r];      // silu(gate) * up (llama.rs MLP)
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < M) C[(size_t)row * ldc + hcol] = cz_siluf(tot[i][0][r]) * tot[i][TN - 1][r];
             }
         }
+        CZ_TAIL_STAMP();
         return;
     }
+    if (full) {
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C + (size_t)(bm * BM) * ldc + bn * BN, 0, 0xffffffffu, 0x00020000);
+        const unsigned loff = ((unsigned)(4 * lh) * (unsigned)ldc + lr) * 4u;
+        if (R) {
+            const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + (size_t)(bm * BM) * ldr + bn * BN), 0, 0xffffffffu, 0x00020000);
+            const unsigned roff = ((unsigned)(4 * lh) * (unsigned)ldr + lr) * 4u;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float rv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, roff, ((wrow + i * 32 + (r & 3) + 8 * (r >> 2)) * ldr + wcol + j * 32) * 4, 0));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tot[i][j][r] + rv[r]), rsC, loff, ((wrow + i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + wcol + j * 32) * 4, 0);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = tot[i][j][r];
+                        if (EPI == 2) { const float z = v > 0.0f ? v : 0.0f; v = z * z; }     // RWKV7 channel-mix key: relu(x)^2 (rwkv7.rs:426)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, loff, ((wrow + i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + wcol + j * 32) * 4, 0);
+                    }
+        }
+        CZ_TAIL_STAMP();
+        return;
+    }
+    // ragged last row tile, or a row mask: per-row predicates
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = bn * BN + (wn * TN + j) * 32 + lr;
+            const int col = col0 + j * 32 + lr;
             // the residual values first, all in flight together (rows past M re-read row M - 1): a load + wait inside a per-element
             // `row < M` branch costs sixteen dependent round trips per tile
             float rv[16];
             if (R) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = min(bm * BM + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1);
+                    const int row = min(row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1);
                     rv[r] = R[(size_t)row * ldr + col];
                 }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = bm * BM + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 float v = R ? tot[i][j][r] + rv[r] : tot[i][j][r];
                 if (EPI == 2) { const float z = tot[i][j][r] > 0.0f ? tot[i][j][r] : 0.0f; v = z * z; }     // RWKV7 channel-mix key: relu(x)^2 (rwkv7.rs:426)
                 if (row < M && (!row_mask || row_mask[row])) C[(size_t)row * ldc + col] = v;       // (row_mask: RWKV literal symbols do not step the model, their logits stay)
             }
         }
+    CZ_TAIL_STAMP();
 }
 
 // ------------------------------------------------------------------------------------------------------------
