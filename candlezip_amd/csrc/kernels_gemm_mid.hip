@@ -96,20 +96,30 @@ __device__ __forceinline__ void gemm_mid_body(const float* __restrict__ A, int l
 
     f32x4 ra[4][2];
     uint4 rb[TN][4];
+    // Addresses as in gemm_bf16w_kernel (round 4): a buffer descriptor at the tile's origin + a per-lane byte offset computed once + a scalar offset
+    // per K tile — the loads of a round cost no vector instruction besides themselves (a vector instruction beside the other waves' MFMA streams
+    // costs ~35 cycles, and twelve waves share a CU here).  Rows past M read row M - 1 (an output row depends on its own activation row only and
+    // the epilogues store rows < M only).
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (size_t)(bm * 32) * lda), 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Wk + (size_t)(bn * (32 * TN)) * K), 0, 0xffffffffu, 0x00020000);
+    const int mrem = M - 1 - bm * 32;
+    unsigned aoff[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) aoff[p] = ((unsigned)min(p * 8 + srow, mrem) * (unsigned)lda + sg * 8) * 4u;
+    const unsigned woff = ((unsigned)lr * (unsigned)K + lh * 32) * 2u;
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            // rows past M read row M - 1 (no branch: a branch per pass serialises the passes' round trips); an output row depends on its own
-            // activation row only and the epilogues store rows < M only
-            const int row = min(bm * 32 + p * 8 + srow, M - 1);
-            const f32x4* src = reinterpret_cast<const f32x4*>(A + (size_t)row * lda + kt * 64 + sg * 8);
-            ra[p][0] = src[0]; ra[p][1] = src[1];
+            ra[p][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff[p], kt * 256, 0));
+            ra[p][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff[p], kt * 256 + 16, 0));
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const uint4* src = reinterpret_cast<const uint4*>(Wk + (size_t)(bn * (32 * TN) + j * 32 + lr) * K + kt * 64 + lh * 32);
-            rb[j][0] = src[0]; rb[j][1] = src[1]; rb[j][2] = src[2]; rb[j][3] = src[3];
-        }
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const auto w = __builtin_amdgcn_raw_buffer_load_b128(rsW, woff, (j * 32 * K + kt * 64) * 2 + q * 16, 0);
+                rb[j][q] = uint4{w[0], w[1], w[2], w[3]};
+            }
     };
     // LDS image (as gemm_bf16w_kernel): within every group of 8 k the even k first, then the odd k, so that the b128 read of lane-half h
     // at 8g + 4h yields k = 8g + 2j + h, j = 0..3 = the A operands of MFMA steps 4g + j
@@ -274,13 +284,53 @@ __device__ __forceinline__ void gemm_mid_body(const float* __restrict__ A, int l
         MST(15);
         return;
     }
+    const bool full = bm * 32 + 32 <= M;                                 // (block-uniform) every row of the tile is stored: scalar row offsets, no predicate
     if (EPI == 1) {
+        if (full) {
+            const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C + (size_t)(bm * 32) * ldc + (bn * (32 * TN)) / 2, 0, 0xffffffffu, 0x00020000);
+            const unsigned loff = ((unsigned)(4 * lh) * (unsigned)ldc + lr) * 4u;
+#pragma unroll
+            for (int e = 0; e < NR; ++e) {
+                const int r = r0 + e;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cz_siluf(tot[0][e]) * tot[TN - 1][e]), rsC, loff, ((r & 3) + 8 * (r >> 2)) * ldc * 4, 0);
+            }
+            MST(15);
+            return;
+        }
         const int hcol = (bn * (32 * TN)) / 2 + lr;
 #pragma unroll
         for (int e = 0; e < NR; ++e) {
             const int r = r0 + e;
             const int row = bm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (row < M) C[(size_t)row * ldc + hcol] = cz_siluf(tot[0][e]) * tot[TN - 1][e];      // silu(gate) * up (llama.rs MLP)
+        }
+        MST(15);
+        return;
+    }
+    if (full) {
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C + (size_t)(bm * 32) * ldc + bn * (32 * TN), 0, 0xffffffffu, 0x00020000);
+        const unsigned loff = ((unsigned)(4 * lh) * (unsigned)ldc + lr) * 4u;
+        if (R) {
+            const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + (size_t)(bm * 32) * ldr + bn * (32 * TN)), 0, 0xffffffffu, 0x00020000);
+            const unsigned roff = ((unsigned)(4 * lh) * (unsigned)ldr + lr) * 4u;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float rv[NR];
+#pragma unroll
+                for (int e = 0; e < NR; ++e) { const int r = r0 + e; rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, roff, (((r & 3) + 8 * (r >> 2)) * ldr + j * 32) * 4, 0)); }
+#pragma unroll
+                for (int e = 0; e < NR; ++e) { const int r = r0 + e; __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tot[j][e] + rv[e]), rsC, loff, (((r & 3) + 8 * (r >> 2)) * ldc + j * 32) * 4, 0); }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < NR; ++e) {
+                    const int r = r0 + e;
+                    float v = tot[j][e];
+                    if (EPI == 3) { const float z = v > 0.0f ? v : 0.0f; v = z * z; }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, loff, (((r & 3) + 8 * (r >> 2)) * ldc + j * 32) * 4, 0);
+                }
         }
         MST(15);
         return;

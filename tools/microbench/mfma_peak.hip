@@ -99,6 +99,42 @@ static void run_shadow(const char* name, int iters) {
     CK(hipFree(out));
 }
 
+// every wave issues NV independent v_fma_f32 after each MFMA (its own VALU work between its own MFMAs): the MFMA rate that is left, for W waves per SIMD
+template <int NV, int SHAPE>   // SHAPE 32: 32x32x2 (64 cycles), 16: 16x16x4 (32 cycles)
+__global__ __launch_bounds__(256) void mix_kernel(float* out, int iters, float a0) {
+    f32x16 acc[4]; f32x4 acc4[4];
+    for (int j = 0; j < 4; ++j) { for (int e = 0; e < 16; ++e) acc[j][e] = 0.f; for (int e = 0; e < 4; ++e) acc4[j][e] = 0.f; }
+    float x[8];
+    for (int j = 0; j < 8; ++j) x[j] = a0 * (j + 1) + threadIdx.x;
+    float a = a0 + threadIdx.x, b = a0;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (SHAPE == 32) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+            else acc4[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc4[j], 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) { x[(j * NV + v) & 7] = __builtin_fmaf(x[(j * NV + v) & 7], 1.0000001f, a0); asm volatile("" : "+v"(x[(j * NV + v) & 7])); }
+        }
+    float s = 0.f;
+    for (int j = 0; j < 4; ++j) { for (int e = 0; e < 16; ++e) s += acc[j][e]; for (int e = 0; e < 4; ++e) s += acc4[j][e]; }
+    for (int j = 0; j < 8; ++j) s += x[j];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+template <int NV, int SHAPE>
+static void run_mix(int waves_per_simd, int iters) {
+    float* out; CK(hipMalloc(&out, 4096));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    mix_kernel<NV, SHAPE><<<256 * waves_per_simd, 256>>>(out, iters / 8, 1e-9f);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    mix_kernel<NV, SHAPE><<<256 * waves_per_simd, 256>>>(out, iters, 1e-9f);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = 256.0 * waves_per_simd * 4 * iters * 4 * (SHAPE == 32 ? 4096.0 : 2048.0);
+    printf("{\"case\": \"mfma %s + %d v_fma per mfma in the same wave\", \"waves_per_simd\": %d, \"tflops\": %.1f}\n", SHAPE == 32 ? "32x32x2" : "16x16x4", NV, waves_per_simd, flops / (ms * 1e-3) / 1e12);
+    CK(hipFree(out));
+}
+
 template <typename F>
 static void run(const char* name, F launch, int blocks_per_cu, int threads, double flops_per_wave_iter, int mf_per_iter, int iters) {
     float* out; CK(hipMalloc(&out, 4096));
@@ -135,6 +171,12 @@ int main() {
     run("16x16x4 acc4 2 waves/simd", L16(4), 2, 256, 4 * 2048.0, 4, it * 2);
     run("16x16x4 acc8 2 waves/simd", L16(8), 2, 256, 8 * 2048.0, 8, it);
     run("16x16x4 acc4 4 waves/simd", L16(4), 4, 256, 4 * 2048.0, 4, it * 2);
+    run_mix<1, 32>(1, 20000); run_mix<2, 32>(1, 20000); run_mix<4, 32>(1, 20000); run_mix<8, 32>(1, 20000); run_mix<12, 32>(1, 20000); run_mix<16, 32>(1, 20000);
+    run_mix<1, 32>(2, 20000); run_mix<2, 32>(2, 20000); run_mix<4, 32>(2, 20000); run_mix<8, 32>(2, 20000); run_mix<12, 32>(2, 20000);
+    run_mix<2, 32>(4, 20000); run_mix<4, 32>(4, 20000); run_mix<8, 32>(4, 20000);
+    run_mix<1, 16>(1, 40000); run_mix<2, 16>(1, 40000); run_mix<4, 16>(1, 40000); run_mix<8, 16>(1, 40000);
+    run_mix<1, 16>(2, 40000); run_mix<2, 16>(2, 40000); run_mix<4, 16>(2, 40000); run_mix<8, 16>(2, 40000);
+    run_mix<1, 16>(4, 40000); run_mix<2, 16>(4, 40000); run_mix<4, 16>(4, 40000);
     run_shadow<0>("v_fma_f32 loop, one wave per SIMD, nothing beside it", 40000);
     run_shadow<1>("v_fma_f32 loop beside a wave streaming 32x32x2 f32 MFMAs on the same SIMD", 40000);
     run_shadow<2>("v_fma_f32 loop beside a wave streaming 16x16x4 f32 MFMAs on the same SIMD", 40000);
