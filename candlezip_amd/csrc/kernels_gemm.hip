@@ -40,7 +40,13 @@ extern "C" void cz_debug_gemm_clock(unsigned long long* out8, int reset) {
     if (reset) { unsigned long long z[32] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_clock), z, sizeof z); }
 }
 #endif
-template <int BM, int BN, int WM, int WN, int EPI>
+#define LDH 36   // LDS row stride of a HALF K tile (32 + 4 floats), PIPE form
+// PIPE (round 4): the K tile is staged as two half tiles of 32 k in two LDS buffers, so that the staging of half h + 1 (bf16 widening, even/odd
+// deinterleave, ds_write) is issued BETWEEN this wave's own MFMAs on half h instead of alone between two barriers: a vector instruction next to
+// the wave's own MFMAs costs the matrix pipe ~3 cycles, alone beside the partner block's MFMA stream ~35 (profiles/r04_gemm_phases/: staging was
+// 3.2 k of the 17.1 k cycles of a K tile).  One barrier per half tile; the accumulator chain of a 64-chunk runs through both halves, so the
+// arithmetic is unchanged.
+template <int BM, int BN, int WM, int WN, int EPI, bool PIPE = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restrict__ A, int lda,
                                                          const uint16_t* __restrict__ W, float* __restrict__ C, int ldc,
                                                          const float* __restrict__ R, int ldr, int M, int N, int K,
@@ -114,11 +120,115 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restr
     constexpr int CKO = 8 * ((BN == 64 ? 1 : 0) + (EPI == 1 ? 2 : 0));      // [0] BN 128 plain (lm_head), [8] BN 64 (q|k|v, o, down), [16] BN 128 SwiGLU (gate|up)
     if (clk) ckin = __builtin_amdgcn_s_memtime();
 #endif
+  if constexpr (PIPE) {
+    static_assert(!PIPE || (BM % 64 == 0 && BN % 64 == 0), "half-tile staging: 64 rows per pass");
+    constexpr int QA = BM / 64, QB = BN / 64;     // staging passes of a half tile (256 threads: 64 rows x 4 quarters of 8 k)
+    const int hrow = tid >> 2, hq = tid & 3;
+    unsigned aoh[QA];
+#pragma unroll
+    for (int p = 0; p < QA; ++p) aoh[p] = ((unsigned)min(p * 64 + hrow, mrem) * (unsigned)lda + hq * 8) * 4u;
+    const unsigned woh = ((unsigned)hrow * (unsigned)K + hq * 8) * 2u;
+    // two register sets: set x is staged (piece by piece, between the MFMA groups of the running half) while set x ^ 1 receives the half after it
+    f32x4 ha[2][QA][2];
+    uint4 hb[2][QB];
+    auto load_half = [&](int x, int h) {          // half tile h: k = 32 h .. 32 h + 31
+#pragma unroll
+        for (int p = 0; p < QA; ++p) {
+            ha[x][p][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoh[p], h * 128, 0));
+            ha[x][p][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoh[p], h * 128 + 16, 0));
+        }
+#pragma unroll
+        for (int p = 0; p < QB; ++p) {
+            const auto w = __builtin_amdgcn_raw_buffer_load_b128(rsW, woh, (p * 64 * K + h * 32) * 2, 0);
+            hb[x][p] = uint4{w[0], w[1], w[2], w[3]};
+        }
+    };
+    // staging pieces 0 .. QA + QB - 1 of register set x into buffer buf: the same even/odd image per group of 8 k as the 64-wide tile
+    auto store_piece = [&](int x, int buf, int q) {
+        float* Ab = smem + buf * ((BM + BN) * LDH);
+        float* Bb = Ab + BM * LDH;
+        if (q < QA) {
+            const int p = q;
+            float* dst = Ab + (p * 64 + hrow) * LDH + hq * 8;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{ha[x][p][0][0], ha[x][p][0][2], ha[x][p][1][0], ha[x][p][1][2]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{ha[x][p][0][1], ha[x][p][0][3], ha[x][p][1][1], ha[x][p][1][3]};
+        } else if (q < QA + QB) {
+            const int p = q - QA;
+            float* dst = Bb + (p * 64 + hrow) * LDH + hq * 8;
+            const uint4 w = hb[x][p];
+            *reinterpret_cast<f32x4*>(dst) = f32x4{cz_bits_f32(w.x << 16), cz_bits_f32(w.y << 16), cz_bits_f32(w.z << 16), cz_bits_f32(w.w << 16)};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{cz_bits_f32(w.x & 0xffff0000u), cz_bits_f32(w.y & 0xffff0000u),
+                                                      cz_bits_f32(w.z & 0xffff0000u), cz_bits_f32(w.w & 0xffff0000u)};
+        }
+    };
+    static_assert(QA + QB <= 4, "one staging piece behind each of the four MFMA groups of a half tile");
+    f32x16 acc[TM][TN];
+    // the half tile in `buf`: four groups of 16 MFMA steps... per accumulator tile 4 steps each (k ascending); behind group g the staging piece g of
+    // register set x goes to the OTHER buffer (stage == false: nothing left to stage)
+    auto mfma_half = [&](int buf, bool first, bool stage, int x) {
+        const float* Ab = smem + buf * ((BM + BN) * LDH);
+        const float* Bb = Ab + BM * LDH;
+        f32x4 af[2][TM], bf[2][TN];                  // operand fragments of group g and, requested before group g's MFMAs, of group g + 1
+        auto frags = [&](int g, int w) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[w][i] = *reinterpret_cast<const f32x4*>(Ab + ((wm * TM + i) * 32 + lr) * LDH + g * 8 + lh * 4);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[w][j] = *reinterpret_cast<const f32x4*>(Bb + ((wn * TN + j) * 32 + lr) * LDH + g * 8 + lh * 4);
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) frags(g + 1, (g + 1) & 1);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if (first && g == 0 && s4 == 0) {
+                            f32x16 z;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][s4], bf[g & 1][j][s4], z, 0, 0, 0);
+                        } else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][s4], bf[g & 1][j][s4], acc[i][j], 0, 0, 0);
+                    }
+            if (stage) store_piece(x, buf ^ 1, g);
+            __builtin_amdgcn_sched_barrier(0);          // (keeps the piece behind ITS group: the scheduler would gather the pieces in front of the first MFMA)
+        }
+    };
+    const int nh = 2 * nk;
+    load_half(0, 0);
+#pragma unroll
+    for (int q = 0; q < QA + QB; ++q) store_piece(0, 0, q);
+    load_half(1, 1);
+#ifdef CZ_GEMM_CLOCK
+    if (clk) { ck0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    for (int c = 0; c < nk; ++c) {
+        // here: buffer 0 holds half 2c (visible after the barrier), register set 1 holds half 2c + 1
+        __syncthreads();
+        if (2 * c + 2 < nh) load_half(0, 2 * c + 2);
+        mfma_half(0, true, true, 1);
+        __syncthreads();                                // buffer 1 staged by every wave; buffer 0 read by every wave
+        if (2 * c + 3 < nh) load_half(1, 2 * c + 3);
+        mfma_half(1, false, 2 * c + 2 < nh, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (c == 0) tot[i][j] = acc[i][j];
+                else
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tot[i][j][r] = tot[i][j][r] + acc[i][j][r];
+            }
+    }
+  } else {
     load_tile(0);
     store_tile();
     __syncthreads();
 #ifdef CZ_GEMM_CLOCK
     if (clk) { ck0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    unsigned long long ksec[4] = {0, 0, 0, 0}, kprev = ck0;
 #endif
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) load_tile(kt + 1);            // global loads in flight under the MFMA chain
@@ -155,9 +265,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restr
 #pragma unroll
                     for (int r = 0; r < 16; ++r) tot[i][j][r] = tot[i][j][r] + acc[i][j][r];
             }
+#ifdef CZ_GEMM_CLOCK
+        // (tuning build) where a K tile's cycles go for wave 0: [24] MFMA section, [25] wait at the barrier behind it, [26] staging stores, [27] wait at the second barrier
+        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        if (clk) s0 = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (clk) s1 = __builtin_amdgcn_s_memtime();
+        if (kt + 1 < nk) { store_tile(); if (clk) s2 = __builtin_amdgcn_s_memtime(); __syncthreads(); }
+        if (clk) {
+            s3 = __builtin_amdgcn_s_memtime();
+            if (CKO == 0) { ksec[0] += s0 - kprev; ksec[1] += s1 - s0; if (kt + 1 < nk) { ksec[2] += s2 - s1; ksec[3] += s3 - s2; } }
+            kprev = s3;
+        }
+#else
         __syncthreads();                                // every wave is done reading this K tile
         if (kt + 1 < nk) { store_tile(); __syncthreads(); }
+#endif
     }
+#ifdef CZ_GEMM_CLOCK
+    if (clk && CKO == 0) for (int q = 0; q < 4; ++q) atomicAdd(&g_gemm_clock[24 + q], ksec[q]);
+#endif
+  }
 #ifdef CZ_GEMM_CLOCK
     unsigned long long ck1 = 0;
     if (clk) {
@@ -325,20 +453,33 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const float* __restric
     }
 }
 
+int g_gemm_pipe = 1;            // cz_debug_set "gemm_pipe": 1 = the 128-row tiles stage half K tiles between their own MFMAs (PIPE), 0 = the one-buffer form
 int g_gemm_lds_kb = 0;          // cz_debug_set "gemm_lds_kb": dynamic LDS per block of the big-M GEMM at least this many KB (0 = what the tiles need)
 template <int BM, int BN, int WM, int WN, int EPI = 0>
 static hipError_t launch_big(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R,
                              int ldr, int M, int N, int K, const unsigned char* row_mask = nullptr) {
+    const int nbx = N / BN, nby = (M + BM - 1) / BM, nblocks = nbx * nby;
+    if constexpr (BM == 128 && BN == 128) {
+        if (g_gemm_pipe) {
+            size_t smem = (size_t)2 * (BM + BN) * LDH * sizeof(float);
+            if ((size_t)g_gemm_lds_kb * 1024 > smem) smem = (size_t)g_gemm_lds_kb * 1024;
+            hipLaunchKernelGGL((gemm_bf16w_kernel<BM, BN, WM, WN, EPI, true>), dim3(nblocks), dim3(256), smem, st, A, lda, W, C, ldc, R, ldr, M, N, K, nbx, nblocks, row_mask);
+            return hipGetLastError();
+        }
+    }
     size_t smem = (size_t)(BM + BN) * LDK * sizeof(float);
     if ((size_t)g_gemm_lds_kb * 1024 > smem) smem = (size_t)g_gemm_lds_kb * 1024;      // tuning knob: fewer GEMM blocks per CU (room for another job's blocks beside them)
     auto kern = gemm_bf16w_kernel<BM, BN, WM, WN, EPI>;        // (its LDS limit is raised by cz_gemm_prepare, once per device at session open)
-    const int nbx = N / BN, nby = (M + BM - 1) / BM, nblocks = nbx * nby;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), smem, st, A, lda, W, C, ldc, R, ldr, M, N, K, nbx, nblocks, row_mask);
     return hipGetLastError();
 }
 
 template <int BM, int BN, int EPI>
 static hipError_t big_prepare() {
+    if constexpr (BM == 128 && BN == 128) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16w_kernel<BM, BN, 2, 2, EPI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
     return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16w_kernel<BM, BN, 2, 2, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // (the tiles need (BM + BN) * LDK * 4; the rest is for the gemm_lds_kb knob)
 }
 // per device, at session open: dynamic-LDS limits of every instantiation the launchers below use (a lazily set process-wide flag would

@@ -1552,14 +1552,14 @@ static cz_status set_stream_priority(cz_session* s, int prio) {
 // The process-wide knobs (the g_* globals of the kernel files) with the values they are shipped with, captured the first time any knob is
 // touched: "reset_process_knobs" puts every one of them back (the tests' fixture finalizer: a test that turned one leaves no trace for
 // the tests that run after it in the same process).
-extern int g_gemv_max_rows, g_gemv_fold_attn, g_cdf_dec_grid_cap, g_gemm_lds_kb, g_attn_v1, g_dec_grid_target, g_dec_nw_cap, g_dec_mt_max, g_dec_norm_mfma, g_gemm_mid_rows, g_mid_nw, g_mid_colmaj, g_mid_quad,
+extern int g_gemv_max_rows, g_gemv_fold_attn, g_cdf_dec_grid_cap, g_gemm_lds_kb, g_gemm_pipe, g_attn_v1, g_dec_grid_target, g_dec_nw_cap, g_dec_mt_max, g_dec_norm_mfma, g_gemm_mid_rows, g_mid_nw, g_mid_colmaj, g_mid_quad,
            g_dec_attn_split_heads, g_dec_attn_lds_pad, g_dec_wide_rows, g_dec_attn_small_grid, g_dec_attn_split_max, g_rw_seq_rows, g_rw_state_pad;
 struct ProcKnob { const char* key; int* p; int shipped; };
 static std::vector<ProcKnob>& proc_knobs() {
     static std::vector<ProcKnob> k;
     if (k.empty()) {
         const std::pair<const char*, int*> all[] = {
-            {"gemv_max_rows", &g_gemv_max_rows}, {"gemv_fold_attn", &g_gemv_fold_attn}, {"cdf_dec_grid_cap", &g_cdf_dec_grid_cap}, {"gemm_lds_kb", &g_gemm_lds_kb}, {"attn_v1", &g_attn_v1}, {"dec_grid_target", &g_dec_grid_target}, {"dec_nw_cap", &g_dec_nw_cap},
+            {"gemv_max_rows", &g_gemv_max_rows}, {"gemv_fold_attn", &g_gemv_fold_attn}, {"cdf_dec_grid_cap", &g_cdf_dec_grid_cap}, {"gemm_lds_kb", &g_gemm_lds_kb}, {"gemm_pipe", &g_gemm_pipe}, {"attn_v1", &g_attn_v1}, {"dec_grid_target", &g_dec_grid_target}, {"dec_nw_cap", &g_dec_nw_cap},
             {"dec_mt_max", &g_dec_mt_max}, {"dec_norm_mfma", &g_dec_norm_mfma}, {"gemm_mid_rows", &g_gemm_mid_rows}, {"mid_nw", &g_mid_nw}, {"mid_colmaj", &g_mid_colmaj},
             {"mid_quad", &g_mid_quad}, {"dec_attn_split_heads", &g_dec_attn_split_heads}, {"dec_attn_lds_pad", &g_dec_attn_lds_pad},
             {"dec_wide_rows", &g_dec_wide_rows}, {"dec_attn_small_grid", &g_dec_attn_small_grid}, {"dec_attn_split_max", &g_dec_attn_split_max},
@@ -1607,6 +1607,7 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "dec_wide_rows")) g_dec_wide_rows = (int)value;
     else if (!strcmp(key, "dec_attn_small_grid")) g_dec_attn_small_grid = (int)value;
     else if (!strcmp(key, "dec_attn_split_max")) g_dec_attn_split_max = (int)value;
+    else if (!strcmp(key, "gemm_pipe")) g_gemm_pipe = (int)value;        // (process-wide) 0: the 128 x 128 tiles of the big-M GEMM on the one-buffer K loop
     else if (!strcmp(key, "gemm_lds_kb")) g_gemm_lds_kb = (int)value < 0 ? 0 : ((int)value > 160 ? 160 : (int)value);   // (process-wide) fewer big-M GEMM blocks per CU
     else if (!strcmp(key, "dbg_skip")) s->dbg_skip = (int)value;          // tools/bench_decode_step.py: 1 = no attention, 2 = no GEMMs/norms (timing only; results are garbage)
     else if (!strcmp(key, "fuse_norm")) s->fuse_norm = (int)value;

@@ -11,6 +11,9 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 s = cz.Session("smollm", cz.smollm2_135m_config(), seed=0x5EED, embed_std=0.02, max_streams=1)
 if len(sys.argv) > 4:
     s.debug_set("attn_v1", int(sys.argv[4]))      # 0 = attention_v2 (default), 1 = the LDS-resident v1 kernel
+for kv in os.environ.get("CZ_BENCH_DEBUG_SET", "").split(","):      # e.g. CZ_BENCH_DEBUG_SET=gemm_pipe=0
+    if "=" in kv:
+        s.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
 if os.environ.get("CZ_ATTN_DBG"):                   # tuning build only (make attn_dbg; CANDLEZIP_AMD_LIB=.../libcandlezip_hip_attndbg.so): results are wrong
     cz.lib().cz_debug_attn_dbg(int(os.environ["CZ_ATTN_DBG"]))
 rng = np.random.default_rng(3)

@@ -39,6 +39,6 @@ fl = sum(v["flops"] for k, v in prof.items() if k.startswith("gemm_bf16w")); ms 
 print(json.dumps({"streams": B, "tokens": T, "clock_ghz_inside_gemm_k_loop": round(ghz, 3),
                   "f32_mfma_peak_at_that_clock_tflops": round(1024 * 64 * ghz / 1e3, 1), "nominal_peak_tflops": 157.3,
                   "gemm_tflops_hip_events": round(fl / ms / 1e9, 1), "frac_of_peak_at_that_clock": round(fl / ms / 1e9 / (1024 * 64 * ghz / 1e3), 3),
-                  "tiles_128x128_lm_head": fam(0, 8192), "tiles_128x128_gate_up_swiglu": fam(16, 8192), "tiles_128x64_qkv_o_down": fam(8, 4096), "gemm_lds_kb": int(sys.argv[3]) if len(sys.argv) > 3 else 0,
+                  "tiles_128x128_lm_head": fam(0, 8192), "lm_head_k_tile_sections_cycles": {"mfma_section": round(out[24] / max(out[3], 1), 1), "wait_barrier_1": round(out[25] / max(out[3], 1), 1), "staging_stores": round(out[26] / max(out[3] - out[2], 1), 1), "wait_barrier_2": round(out[27] / max(out[3] - out[2], 1), 1)}, "tiles_128x128_gate_up_swiglu": fam(16, 8192), "tiles_128x64_qkv_o_down": fam(8, 4096), "gemm_lds_kb": int(sys.argv[3]) if len(sys.argv) > 3 else 0,
                   "compress_tokens_per_s": round(2 * B * T / dt, 1)}))
 s.close()
