@@ -138,6 +138,7 @@ def lib():
         "cz_debug_get": (C.c_long, [vp, C.c_char_p]),
         "cz_debug_attention": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
         "cz_debug_attn_variant": (None, [C.c_int]),
+        "cz_debug_expf_exhaustive": (C.c_int, [vp]),
     }
     for name, (res, args) in sig.items():
         if hasattr(L, name):

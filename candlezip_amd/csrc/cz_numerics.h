@@ -22,7 +22,8 @@ CZ_HD float cz_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); 
 
 // exp: Cody-Waite reduction by ln2 (hi/lo), degree-5 polynomial, two-step 2^n scaling (one rounding for
 // subnormal results).  exp(-inf) = 0, exp(x > 88.73) = +inf, NaN propagates.
-CZ_HD float cz_expf(float x) {
+// The definition (host, oracle, and the yardstick of the device form below).
+CZ_HD float cz_expf_ref(float x) {
     if (x != x) return x;
     if (x < -104.0f) x = -104.0f;
     if (x > 89.0f) x = 89.0f;
@@ -45,6 +46,35 @@ CZ_HD float cz_expf(float x) {
     float s1 = cz_bits_f32((uint32_t)(k1 + 127) << 23);
     float s2 = cz_bits_f32((uint32_t)(k2 + 127) << 23);
     return (y * s1) * s2;
+}
+// Device form, the SAME function (round 4): the clamps as v_max / v_min (a NaN is put back by the last select), the two-step 2^n scaling as ONE
+// v_ldexp_f32 — y * 2^k1 is exact (k1 in [-75, 64], y in [0.5, 2.8)) and the second product rounds once, which is what ldexp does — 20 vector
+// instructions instead of 31.  A vector instruction costs the matrix pipe of its SIMD ~3 cycles (35 beside another wave's MFMA stream), and the
+// GEMM's SwiGLU epilogue, the prefill attention and the CDF kernels are made of these.  tests/test_gpu_round4.py compares the two forms on ALL
+// 2^32 float bit patterns on the device (cz_debug_expf_exhaustive): zero differences.
+CZ_HD float cz_expf(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float xc = __builtin_fminf(__builtin_fmaxf(x, -104.0f), 89.0f);
+    const float MAGIC = 12582912.0f;
+    float t = cz_fma(xc, 1.44269504088896341f, MAGIC);
+    float n = t - MAGIC;
+    int ni = (int)n;
+    float r = cz_fma(n, -0.693145751953125f, xc);
+    r = cz_fma(n, -1.42860682030941723e-06f, r);
+    float p = 1.9875691500e-4f;
+    p = cz_fma(p, r, 1.3981999507e-3f);
+    p = cz_fma(p, r, 8.3334519073e-3f);
+    p = cz_fma(p, r, 4.1665795894e-2f);
+    p = cz_fma(p, r, 1.6666665459e-1f);
+    p = cz_fma(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = cz_fma(p, r2, r);
+    y = y + 1.0f;
+    const float res = __builtin_amdgcn_ldexpf(y, ni);
+    return x != x ? x : res;
+#else
+    return cz_expf_ref(x);
+#endif
 }
 
 CZ_HD float cz_logf(float x) {

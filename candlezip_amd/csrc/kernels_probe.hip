@@ -48,6 +48,30 @@ __global__ void f64_fn_kernel(int fn, const double* x, const double* y, double* 
     out[i] = r;
 }
 
+// every float bit pattern through the device form of cz_expf and through its definition: out[0] = number of inputs whose results differ in any bit,
+// out[1] = the first such input's bits (lowest), out[2] = inputs compared
+__global__ void expf_exhaustive_kernel(unsigned long long* out) {
+    unsigned long long bad = 0, first = ~0ull;
+    for (unsigned long long u = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u < (1ull << 32); u += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = cz_bits_f32((uint32_t)u);
+        if (cz_f32_bits(cz_expf(x)) != cz_f32_bits(cz_expf_ref(x))) { ++bad; if (u < first) first = u; }
+    }
+    if (bad) { atomicAdd(&out[0], bad); atomicMin(&out[1], first); }
+    if (threadIdx.x == 0) atomicAdd(&out[2], 0ull);
+}
+extern "C" cz_status cz_debug_expf_exhaustive(unsigned long long* out3) {
+    DevMem m;
+    unsigned long long* d = (unsigned long long*)m.alloc(24);
+    if (!d) { cz_set_error("hipMalloc failed"); return CZ_ERR_HIP; }
+    const unsigned long long init[3] = {0, ~0ull, 1ull << 32};
+    PCHK(hipMemcpy(d, init, 24, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(expf_exhaustive_kernel, dim3(4096), dim3(256), 0, 0, d);
+    PCHK(hipGetLastError());
+    PCHK(hipMemcpy(out3, d, 24, hipMemcpyDeviceToHost));
+    return CZ_OK;
+fail:
+    return CZ_ERR_HIP;
+}
 extern "C" cz_status cz_debug_scalar(int fn, const float* x, const float* y, float* out, int n) {
     DevMem m;
     float *dx = (float*)m.alloc(n * 4), *dy = (float*)m.alloc(n * 4), *dout = (float*)m.alloc(n * 4);

@@ -162,3 +162,14 @@ def test_groups_at_the_wide_step_thresholds_round_trip(cz, czo, backend, n_strea
     for a, b in zip(outs[:36], outs2):
         assert np.array_equal(a, b)
     g2.close(); o.close()
+
+
+def test_device_expf_equals_its_definition_on_every_float(cz):
+    """round 4: the device form of cz_expf (clamps as v_max / v_min, ONE v_ldexp_f32 instead of the two-step 2^n scaling; cz_numerics.h) against the definition
+    (cz_expf_ref, the form the host code and the oracle's restatement use) on ALL 2^32 float bit patterns — NaNs, infinities, subnormal results included —
+    on the device: not one differing bit."""
+    import ctypes as C
+    out = (C.c_ulonglong * 3)()
+    assert cz.lib().cz_debug_expf_exhaustive(out) == 0
+    assert out[2] == 1 << 32
+    assert out[0] == 0, "device cz_expf differs from its definition on %d inputs, the first: bits 0x%08x" % (out[0], out[1])
