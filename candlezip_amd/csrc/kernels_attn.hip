@@ -173,8 +173,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 __device__ int g_attn_dbg_dev;
 extern "C" void cz_debug_attn_dbg(int v) { hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbg_dev), &v, sizeof v); }
 #define ADBG(bit) (dbg & (bit))
+// phase stamps (shader-clock cycles, thread 0 of the blocks (tile & 15) == 15 whose tile has all NI chunks): [0] blocks, [1] Q load .. first K staged, [2] phase 1 (scores),
+// [3] phase 2 (row maxima), [4] phase 3 (exp + row sums), [5] sums combined, [6] phase 4 (p, P.V), [7] output stores; [8] chunks
+__device__ unsigned long long g_attn_stamp[16];
+extern "C" void cz_debug_attn_stamps(unsigned long long* out16, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_attn_stamp), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamp), z, sizeof z); }
+}
+#define AST_BEGIN const bool ast_on = threadIdx.x == 0 && (blockIdx.x & 15) == 15 && nch == NI; unsigned long long ast_t = ast_on ? __builtin_amdgcn_s_memtime() : 0
+#define AST(ph) do { if (ast_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_attn_stamp[ph], t_ - ast_t); ast_t = t_; } } while (0)
 #else
 #define ADBG(bit) false
+#define AST_BEGIN do { } while (0)
+#define AST(ph) do { } while (0)
 #endif
 #define V2_KS 68
 #define V2_VS 80
@@ -204,6 +216,7 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
 #ifdef CZ_ATTN_DBG
     const int dbg = g_attn_dbg_dev;
 #endif
+    AST_BEGIN;
     // A operand of QK^T: lane (i = li, g = lg) holds Q[row i][head][d = 4t + g].  Where the score tiles alone fill most of the register
     // file (REP * NI >= 48: 192 VGPRs of S) the operand lives in LDS instead — lane-contiguous, so a chunk re-reads it with four
     // ds_read_b128 per head — and the kernel stays under 256 VGPRs without scratch (it spilled 64 registers per lane before).  The
@@ -234,36 +247,47 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
     f32x4 S[NI][REP];
     // K / V chunk loads: one block per CU and one wave per SIMD leave nothing else to hide a miss behind, so the NEXT chunk's four
     // 16-B pieces per thread are fetched into registers while the current chunk's MFMAs run
-    auto load_k = [&](int c, f32x4* out) {
-        if (ADBG(32)) { out[0] = out[1] = out[2] = out[3] = f32x4{0.5f, 0.25f, 0.125f, 1.0f}; return; }
+    // K (row layout) and V chunk loads: descriptor at the sequence's rows of this KV head, a per-lane byte offset inside the chunk (one v_add per pass) clamped by
+    // ONE v_min to the chunk's last valid row, the chunk's base as a scalar offset — no 64-bit address arithmetic, no zero-fill (round 4: a vector instruction
+    // of this kernel costs 20-35 cycles beside the other block's MFMA bursts; clamps, address arithmetic and zero-fills were ~65 of a score chunk's ~130).
+    // Rows past nk_blk re-read the last valid row: their scores are masked to -inf below (key > every row's position), so their p is exactly 0 and
+    // fma(0, v, acc) == acc for the finite v of a valid row — the same bits as the zero padding of the definition.
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sd.k + kvh * 64), 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sd.v + kvh * 64), 0, 0xffffffffu, 0x00020000);
+    const unsigned kv_lane_off_ = ((unsigned)(tid >> 4) * (unsigned)sd.kv_stride + (tid & 15) * 4) * 4u;
+    auto load_rows = [&](const __amdgpu_buffer_rsrc_t rs, int c, f32x4* out) {
+        unsigned t = tid, kv_lane_off = kv_lane_off_;
+        if (REP * NI <= 24) {                                          // the 168-register variants: re-derive the lane's offsets per call (five VALU) instead of keeping them live (they spilled)
+            asm volatile("" : "+v"(t));
+            kv_lane_off = ((t >> 4) * (unsigned)sd.kv_stride + (t & 15) * 4) * 4u;
+        }
+        const unsigned lim = (unsigned)(nk_blk - 1 - c * 64) * (unsigned)sd.kv_stride * 4u + (t & 15) * 16u;     // this lane's piece of the chunk's last valid row
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
+            const unsigned off = min(kv_lane_off + (unsigned)(16 * p) * (unsigned)sd.kv_stride * 4u, lim);
+            out[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, c * 64 * sd.kv_stride * 4, 0));
+        }
+    };
+    auto load_k = [&](int c, f32x4* out) {
+        if (ADBG(32)) { out[0] = out[1] = out[2] = out[3] = f32x4{0.5f, 0.25f, 0.125f, 1.0f}; return; }
+        if (!sd.kt_stride) { load_rows(rsK, c, out); return; }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {                                  // the decode cache's transposed K (re-prime): k[(kvh*64 + d) * kt_stride + j]
             const int key = (tid >> 4) + 16 * p, q4 = tid & 15;
             const int j = c * 64 + key;
-            const int jj = j < nk_blk ? j : nk_blk - 1;               // clamp (never a conditional load), zero afterwards
-            f32x4 v;
-            if (sd.kt_stride) {
-                const float* kp = sd.k + (size_t)(kvh * 64 + q4 * 4) * sd.kt_stride + jj;
-                v = f32x4{kp[0], kp[sd.kt_stride], kp[2 * (size_t)sd.kt_stride], kp[3 * (size_t)sd.kt_stride]};
-            } else v = *reinterpret_cast<const f32x4*>(sd.k + (size_t)jj * sd.kv_stride + kvh * 64 + q4 * 4);
-            if (j >= nk_blk) v = f32x4{0, 0, 0, 0};
-            out[p] = v;
+            const int jj = j < nk_blk ? j : nk_blk - 1;               // clamp (never a conditional load)
+            const float* kp = sd.k + (size_t)(kvh * 64 + q4 * 4) * sd.kt_stride + jj;
+            out[p] = f32x4{kp[0], kp[sd.kt_stride], kp[2 * (size_t)sd.kt_stride], kp[3 * (size_t)sd.kt_stride]};
         }
     };
     auto load_v = [&](int c, f32x4* out) {
         if (ADBG(32)) { out[0] = out[1] = out[2] = out[3] = f32x4{0.5f, 0.25f, 0.125f, 1.0f}; return; }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int key = (tid >> 4) + 16 * p, q4 = tid & 15;
-            const int j = c * 64 + key;
-            const int jj = j < nk_blk ? j : nk_blk - 1;
-            f32x4 v = *reinterpret_cast<const f32x4*>(sd.v + (size_t)jj * sd.kv_stride + kvh * 64 + q4 * 4);
-            if (j >= nk_blk) v = f32x4{0, 0, 0, 0};
-            out[p] = v;
-        }
+        load_rows(rsV, c, out);
     };
     f32x4 pre[4];
     load_k(0, pre);
+    const int klim0 = sd.pos0 + tile * 16 + 4 * lg;                    // the last key this lane's query row r may see is klim0 + r
+    AST(1);
     // ---- phase 1: scores
 #pragma unroll
     for (int c = 0; c < NI; ++c) {
@@ -281,7 +305,7 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
 #pragma unroll
                 for (int t = 0; t < 16; ++t) kb[t] = kbp[4 * t];
             }
-            const int key = c * 64 + wave * 16 + li;
+            const int key = c * 64 + wave * 16 + li, dk = key - klim0;
 #pragma unroll
             for (int rt = 0; rt < REP; ++rt) {
                 f32x4 acc = f32x4{0, 0, 0, 0};
@@ -300,16 +324,16 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {                               // C/D: col = li -> key ; row = 4*lg + r -> query row
-                    const int qr = 4 * lg + r;
                     float v = acc[r] * 0.125f;
-                    if (qr >= rows_here || key > sd.pos0 + tile * 16 + qr) v = -INFINITY;
-                    S[c][rt][r] = v;
+                    if (dk > r) v = -INFINITY;                              // causal mask: key > klim0 + r (rows past rows_here: zero queries, never stored — no mask of their own)
+                    S[c][rt][r] = v;                                        // (a block-uniform branch that skips the mask off the diagonal costs 430 spilled registers: the score tiles cross it)
                 }
             }
             if (!DB) __syncthreads();                                   // (DB: the next chunk goes to the other buffer; the one after that is past the next barrier)
         }
     }
     load_v(0, pre);                                                    // first V chunk: in flight during the softmax phases
+    AST(2);
     // ---- phase 2: row max (exact in any order)
     float gmax[REP][4];
 #pragma unroll
@@ -334,12 +358,13 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
             for (int w = 1; w < 4; ++w) m = wred[w][s] > m ? wred[w][s] : m;
             gmax[rt][r] = m;
         }
+    AST(3);
     // ---- phase 3: e = exp(s - max); canonical row sums (sequential inside a 64-key chunk, chunks left to right)
     // canonical chunk sum of a head's 16 rows (acc = acc + e_k, k ascending from 0) on the MFMA: with B = 1 the chain fma(e_k, 1, acc) rounds
     // e_k + acc once — the same bits as the add — and sixteen 16x16x4 steps replace 64 dependent LDS reads + adds
     auto exp_elem = [&](int c, int rt, int r, float* Et) {
         const int qr = 4 * lg + r;
-        const float e = qr < rows_here ? (ADBG(2) ? S[c][rt][r] - gmax[rt][r] : cz_expf(S[c][rt][r] - gmax[rt][r])) : 0.0f;
+        const float e = ADBG(2) ? S[c][rt][r] - gmax[rt][r] : cz_expf(S[c][rt][r] - gmax[rt][r]);      // (rows past rows_here: zero queries, finite values, never stored)
         S[c][rt][r] = e;
         Et[(rt * 16 + qr) * V2_KS + wave * 16 + li] = e;
     };
@@ -370,12 +395,14 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
         }
         if (DB) __syncthreads();                                        // csum complete
     }
+    AST(4);
     if (tid < REP * 16) {
         float t = csum[tid][0];
         for (int c = 1; c < nch; ++c) t = t + csum[tid][c];
         rsum[tid] = t;
     }
     __syncthreads();
+    AST(5);
     float rs[REP][4];
 #pragma unroll
     for (int rt = 0; rt < REP; ++rt)
@@ -395,7 +422,7 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qr = 4 * lg + r;
-                    Et[(rt * 16 + qr) * V2_KS + wave * 16 + li] = qr < rows_here ? (ADBG(8) ? S[c][rt][r] : S[c][rt][r] / rs[rt][r]) : 0.0f;
+                    Et[(rt * 16 + qr) * V2_KS + wave * 16 + li] = ADBG(8) ? S[c][rt][r] : S[c][rt][r] / rs[rt][r];
                 }
 #pragma unroll
             for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(stage + ((tid >> 4) + 16 * p) * V2_VS + (tid & 15) * 4) = pre[p];
@@ -423,6 +450,7 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
             if (!DB) __syncthreads();
         }
     }
+    AST(6);
 #pragma unroll
     for (int rt = 0; rt < REP; ++rt)
 #pragma unroll
@@ -430,6 +458,10 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
             const int qr = 4 * lg + r;
             if (qr < rows_here) O[(size_t)(row_base + qr) * ldo + (kvh * REP + rt) * 64 + wave * 16 + li] = tot[rt][r];
         }
+    AST(7);
+#ifdef CZ_ATTN_DBG
+    if (ast_on) { atomicAdd(&g_attn_stamp[0], 1ull); atomicAdd(&g_attn_stamp[8], (unsigned long long)nch); }
+#endif
 }
 // ------------------------------------------------------------------------------------------------------------
 // attention_v3_kernel<REP>: the same arithmetic for ANY context length (re-prime intervals past 1536 tokens: a segment of up to

@@ -31,4 +31,12 @@ print(json.dumps({"streams": B, "tokens": T, "compress_tokens_per_s": round(reps
                   "families_launches": {k: v["launches"] for k, v in prof.items()},
                   "gemm_tflops": round(sum(v["flops"] for k, v in prof.items() if k.startswith("gemm")) / max(sum(v["total_ms"] for k, v in prof.items() if k.startswith("gemm")), 1e-9) / 1e9, 1),
                   "attention_tflops": round(prof.get("attention_f32_mfma", {"flops": 0})["flops"] / max(prof.get("attention_f32_mfma", {"total_ms": 1e-9})["total_ms"], 1e-9) / 1e9, 1)}))
+if os.environ.get("CZ_ATTN_DBG") is not None and hasattr(cz.lib(), "cz_debug_attn_stamps"):
+    import ctypes as C
+    o = (C.c_ulonglong * 16)()
+    cz.lib().cz_debug_attn_stamps(o, 0)
+    nb, nc = max(o[0], 1), max(o[8], 1)
+    print(json.dumps({"attention_v2_phase_cycles_per_block": {"sampled_blocks": int(o[0]), "chunks_per_block": round(nc / nb, 1), "q_and_first_k": round(o[1] / nb), "phase1_scores": round(o[2] / nb),
+          "phase2_max": round(o[3] / nb), "phase3_exp_sums": round(o[4] / nb), "sums_combined": round(o[5] / nb), "phase4_p_pv": round(o[6] / nb), "stores": round(o[7] / nb),
+          "phase1_per_chunk": round(o[2] / nc), "phase3_per_chunk": round(o[4] / nc), "phase4_per_chunk": round(o[6] / nc)}}))
 s.close()
