@@ -287,6 +287,9 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
     f32x4 pre[4];
     load_k(0, pre);
     const int klim0 = sd.pos0 + tile * 16 + 4 * lg;                    // the last key this lane's query row r may see is klim0 + r
+    // e / p tiles: key k of the chunk lives at column (k & 3) * 16 + (k >> 2) of its row, so that the A operand of MFMA step t — key 4t + lg — is column
+    // lg * 16 + t: a lane reads its sixteen operands as FOUR ds_read_b128 instead of eight ds_read2_b32, each of which the two MFMAs behind it waited for
+    const int kperm = (li & 3) * 16 + wave * 4 + (li >> 2);            // this lane's key wave * 16 + li
     AST(1);
     // ---- phase 1: scores
 #pragma unroll
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
         const int qr = 4 * lg + r;
         const float e = ADBG(2) ? S[c][rt][r] - gmax[rt][r] : cz_expf(S[c][rt][r] - gmax[rt][r]);      // (rows past rows_here: zero queries, finite values, never stored)
         S[c][rt][r] = e;
-        Et[(rt * 16 + qr) * V2_KS + wave * 16 + li] = e;
+        Et[(rt * 16 + qr) * V2_KS + kperm] = e;
     };
     // (Issuing chunk c's sixteen dependent sum MFMAs between the exponentials of chunk c + 1 was tried: the longer live ranges cost 24
     // spilled registers at <3,16> and the kernel got 6 % slower, call27.)
@@ -381,10 +384,14 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
                     for (int r = 0; r < 4; ++r) exp_elem(c, rt, r, Et);
                 __syncthreads();
                 if (wave < REP && !ADBG(4)) {
-                    const float* pa = Et + (wave * 16 + li) * V2_KS + lg;            // A[i = li][k = 4t + lg] = e[row][key]
+                    const f32x4* pa4 = reinterpret_cast<const f32x4*>(Et + (wave * 16 + li) * V2_KS + lg * 16);      // A[i = li][k = 4t + lg] = e[row][key]: column lg * 16 + t
                     f32x4 sacc = f32x4{0, 0, 0, 0};
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * t], 1.0f, sacc, 0, 0, 0);
+                    for (int t4 = 0; t4 < 4; ++t4) {
+                        const f32x4 a = pa4[t4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], 1.0f, sacc, 0, 0, 0);
+                    }
                     if (li == 0) {                                                    // C/D: row = 4*lg + r; every column holds the same sum
 #pragma unroll
                         for (int r = 0; r < 4; ++r) csum[wave * 16 + 4 * lg + r][c] = sacc[r];
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qr = 4 * lg + r;
-                    Et[(rt * 16 + qr) * V2_KS + wave * 16 + li] = ADBG(8) ? S[c][rt][r] : S[c][rt][r] / rs[rt][r];
+                    Et[(rt * 16 + qr) * V2_KS + kperm] = ADBG(8) ? S[c][rt][r] : S[c][rt][r] / rs[rt][r];
                 }
 #pragma unroll
             for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(stage + ((tid >> 4) + 16 * p) * V2_VS + (tid & 15) * 4) = pre[p];
@@ -436,12 +443,16 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
             }
 #pragma unroll
             for (int rt = 0; rt < REP; ++rt) {
-                const float* pa = Et + (rt * 16 + li) * V2_KS + lg;          // A[i = li][k = 4t + lg] = P[row][key]
+                const f32x4* pa4 = reinterpret_cast<const f32x4*>(Et + (rt * 16 + li) * V2_KS + lg * 16);      // A[i = li][k = 4t + lg] = P[row][key]: column lg * 16 + t
                 f32x4 acc = f32x4{0, 0, 0, 0};
-                if (ADBG(16)) acc[0] = pa[0];
+                if (ADBG(16)) acc[0] = pa4[0][0];
                 else
 #pragma unroll
-                for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * t], QLDS ? vbp[4 * t * V2_VS] : vb[t], acc, 0, 0, 0);
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const f32x4 a = pa4[t4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], QLDS ? vbp[4 * (4 * t4 + t) * V2_VS] : vb[4 * t4 + t], acc, 0, 0, 0);
+                }
                 if (c == 0) tot[rt] = acc;
                 else
 #pragma unroll
