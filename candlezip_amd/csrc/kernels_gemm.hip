@@ -40,14 +40,15 @@ extern "C" void cz_debug_gemm_clock(unsigned long long* out8, int reset) {
     if (reset) { unsigned long long z[32] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_clock), z, sizeof z); }
 }
 #endif
-#define LDH 36   // LDS row stride of a HALF K tile (32 + 4 floats), PIPE form
+#define LDH 32   // LDS row stride of a HALF K tile, PIPE form: unpadded; the 16-byte column c of row r lives at column c ^ ((r >> 1) & 7) — conflict-free
+                 // ds_read_b128 by 16 consecutive rows and ds_write_b128 by 4 rows x 4 column pairs, and three 128 x 64 blocks (3 x 48 KB) share a CU
 // PIPE (round 4): the K tile is staged as two half tiles of 32 k in two LDS buffers, so that the staging of half h + 1 (bf16 widening, even/odd
 // deinterleave, ds_write) is issued BETWEEN this wave's own MFMAs on half h instead of alone between two barriers: a vector instruction next to
 // the wave's own MFMAs costs the matrix pipe ~3 cycles, alone beside the partner block's MFMA stream ~35 (profiles/r04_gemm_phases/: staging was
 // 3.2 k of the 17.1 k cycles of a K tile).  One barrier per half tile; the accumulator chain of a 64-chunk runs through both halves, so the
 // arithmetic is unchanged.
 template <int BM, int BN, int WM, int WN, int EPI, bool PIPE = false>
-__global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restrict__ A, int lda,
+__global__ __launch_bounds__(256, (PIPE && BM + BN <= 192) ? 3 : 2) void gemm_bf16w_kernel(const float* __restrict__ A, int lda,
                                                          const uint16_t* __restrict__ W, float* __restrict__ C, int ldc,
                                                          const float* __restrict__ R, int ldr, int M, int N, int K,
                                                          int nbx, int nblocks, const unsigned char* __restrict__ row_mask) {
@@ -131,6 +132,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restr
     // two register sets: set x is staged (piece by piece, between the MFMA groups of the running half) while set x ^ 1 receives the half after it
     f32x4 ha[2][QA][2];
     uint4 hb[2][QB];
+    // float offsets inside a half-tile image: this thread's even-k / odd-k quads of 8-group hq of row hrow (columns 2 hq and 2 hq + 1, swizzled), and this
+    // lane's operand quad of group g (column 2 g + lh of row lr, swizzled) — computed once
+    const int wsw = (hrow >> 1) & 7, rsw = (lr >> 1) & 7;
+    const int wev = hrow * LDH + ((2 * hq) ^ wsw) * 4, wod = hrow * LDH + ((2 * hq + 1) ^ wsw) * 4;
+    int rof[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rof[g] = lr * LDH + ((2 * g + lh) ^ rsw) * 4;
     auto load_half = [&](int x, int h) {          // half tile h: k = 32 h .. 32 h + 31
 #pragma unroll
         for (int p = 0; p < QA; ++p) {
@@ -149,15 +157,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restr
         float* Bb = Ab + BM * LDH;
         if (q < QA) {
             const int p = q;
-            float* dst = Ab + (p * 64 + hrow) * LDH + hq * 8;
-            *reinterpret_cast<f32x4*>(dst) = f32x4{ha[x][p][0][0], ha[x][p][0][2], ha[x][p][1][0], ha[x][p][1][2]};
-            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{ha[x][p][0][1], ha[x][p][0][3], ha[x][p][1][1], ha[x][p][1][3]};
+            float* dst = Ab + p * 64 * LDH;                           // (the swizzle of row p * 64 + hrow is that of row hrow)
+            *reinterpret_cast<f32x4*>(dst + wev) = f32x4{ha[x][p][0][0], ha[x][p][0][2], ha[x][p][1][0], ha[x][p][1][2]};
+            *reinterpret_cast<f32x4*>(dst + wod) = f32x4{ha[x][p][0][1], ha[x][p][0][3], ha[x][p][1][1], ha[x][p][1][3]};
         } else if (q < QA + QB) {
             const int p = q - QA;
-            float* dst = Bb + (p * 64 + hrow) * LDH + hq * 8;
+            float* dst = Bb + p * 64 * LDH;
             const uint4 w = hb[x][p];
-            *reinterpret_cast<f32x4*>(dst) = f32x4{cz_bits_f32(w.x << 16), cz_bits_f32(w.y << 16), cz_bits_f32(w.z << 16), cz_bits_f32(w.w << 16)};
-            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{cz_bits_f32(w.x & 0xffff0000u), cz_bits_f32(w.y & 0xffff0000u),
+            *reinterpret_cast<f32x4*>(dst + wev) = f32x4{cz_bits_f32(w.x << 16), cz_bits_f32(w.y << 16), cz_bits_f32(w.z << 16), cz_bits_f32(w.w << 16)};
+            *reinterpret_cast<f32x4*>(dst + wod) = f32x4{cz_bits_f32(w.x & 0xffff0000u), cz_bits_f32(w.y & 0xffff0000u),
                                                       cz_bits_f32(w.z & 0xffff0000u), cz_bits_f32(w.w & 0xffff0000u)};
         }
     };
@@ -171,9 +179,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(const float* __restr
         f32x4 af[2][TM], bf[2][TN];                  // operand fragments of group g and, requested before group g's MFMAs, of group g + 1
         auto frags = [&](int g, int w) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[w][i] = *reinterpret_cast<const f32x4*>(Ab + ((wm * TM + i) * 32 + lr) * LDH + g * 8 + lh * 4);
+            for (int i = 0; i < TM; ++i) af[w][i] = *reinterpret_cast<const f32x4*>(Ab + (wm * TM + i) * 32 * LDH + rof[g]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[w][j] = *reinterpret_cast<const f32x4*>(Bb + ((wn * TN + j) * 32 + lr) * LDH + g * 8 + lh * 4);
+            for (int j = 0; j < TN; ++j) bf[w][j] = *reinterpret_cast<const f32x4*>(Bb + (wn * TN + j) * 32 * LDH + rof[g]);
         };
         frags(0, 0);
 #pragma unroll
@@ -453,14 +461,14 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const float* __restric
     }
 }
 
-int g_gemm_pipe = 1;            // cz_debug_set "gemm_pipe": 1 = the 128-row tiles stage half K tiles between their own MFMAs (PIPE), 0 = the one-buffer form
+int g_gemm_pipe = 3;            // cz_debug_set "gemm_pipe": bit 0 = the 128 x 128 tiles, bit 1 = the 128 x 64 tiles stage half K tiles between their own MFMAs (PIPE); 0 = the one-buffer form
 int g_gemm_lds_kb = 0;          // cz_debug_set "gemm_lds_kb": dynamic LDS per block of the big-M GEMM at least this many KB (0 = what the tiles need)
 template <int BM, int BN, int WM, int WN, int EPI = 0>
 static hipError_t launch_big(hipStream_t st, const float* A, int lda, const uint16_t* W, float* C, int ldc, const float* R,
                              int ldr, int M, int N, int K, const unsigned char* row_mask = nullptr) {
     const int nbx = N / BN, nby = (M + BM - 1) / BM, nblocks = nbx * nby;
-    if constexpr (BM == 128 && BN == 128) {
-        if (g_gemm_pipe) {
+    if constexpr (BM == 128) {
+        if (BN == 128 ? (g_gemm_pipe & 1) : (g_gemm_pipe & 2)) {             // bit 0: the 128 x 128 tiles, bit 1: the 128 x 64 tiles (two blocks per CU instead of three)
             size_t smem = (size_t)2 * (BM + BN) * LDH * sizeof(float);
             if ((size_t)g_gemm_lds_kb * 1024 > smem) smem = (size_t)g_gemm_lds_kb * 1024;
             hipLaunchKernelGGL((gemm_bf16w_kernel<BM, BN, WM, WN, EPI, true>), dim3(nblocks), dim3(256), smem, st, A, lda, W, C, ldc, R, ldr, M, N, K, nbx, nblocks, row_mask);
@@ -476,7 +484,7 @@ static hipError_t launch_big(hipStream_t st, const float* A, int lda, const uint
 
 template <int BM, int BN, int EPI>
 static hipError_t big_prepare() {
-    if constexpr (BM == 128 && BN == 128) {
+    if constexpr (BM == 128) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16w_kernel<BM, BN, 2, 2, EPI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
