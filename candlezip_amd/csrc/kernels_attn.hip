@@ -181,8 +181,9 @@ extern "C" void cz_debug_attn_stamps(unsigned long long* out16, int reset) {
     hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_attn_stamp), sizeof(unsigned long long) * 16);
     if (reset) { unsigned long long z[16] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamp), z, sizeof z); }
 }
-#define AST_BEGIN const bool ast_on = threadIdx.x == 0 && (blockIdx.x & 15) == 15 && nch == NI; unsigned long long ast_t = ast_on ? __builtin_amdgcn_s_memtime() : 0
+#define AST_BEGIN const bool ast_on = threadIdx.x == 0 && (blockIdx.x & 15) == 15 && nch == NI; unsigned long long ast_t = ast_on ? __builtin_amdgcn_s_memtime() : 0, ast_t2 = ast_t
 #define AST(ph) do { if (ast_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_attn_stamp[ph], t_ - ast_t); ast_t = t_; } } while (0)
+#define AST2(ph) do { if (ast_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_attn_stamp[ph], t_ - ast_t2); ast_t2 = t_; } } while (0)
 #else
 #define ADBG(bit) false
 #define AST_BEGIN do { } while (0)
@@ -291,6 +292,9 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
     // lg * 16 + t: a lane reads its sixteen operands as FOUR ds_read_b128 instead of eight ds_read2_b32, each of which the two MFMAs behind it waited for
     const int kperm = (li & 3) * 16 + wave * 4 + (li >> 2);            // this lane's key wave * 16 + li
     AST(1);
+#ifdef CZ_ATTN_DBG
+    ast_t2 = ast_t;
+#endif
     // ---- phase 1: scores
 #pragma unroll
     for (int c = 0; c < NI; ++c) {
@@ -298,9 +302,16 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
         for (int rt = 0; rt < REP; ++rt) S[c][rt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         if (c < nch) {
             float* stage = stage_of(c);
+#ifdef CZ_ATTN_DBG
+            if (ast_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            AST2(9);                                                   // (tuning build) [9] wait for this chunk's K in registers, [10] stage it + barrier, [11] the rest of the chunk
+#endif
 #pragma unroll
             for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(stage + ((tid >> 4) + 16 * p) * V2_KS + (tid & 15) * 4) = pre[p];
             __syncthreads();
+#ifdef CZ_ATTN_DBG
+            AST2(10);
+#endif
             if (c + 1 < nch) load_k(c + 1, pre);                       // in flight during the MFMAs below
             float kb[16];
             const float* kbp = stage + (wave * 16 + li) * V2_KS + lg;
@@ -333,6 +344,9 @@ __global__ __launch_bounds__(256, (REP * NI <= 24 ? 3 : REP * NI <= 48 ? 2 : 1))
                 }
             }
             if (!DB) __syncthreads();                                   // (DB: the next chunk goes to the other buffer; the one after that is past the next barrier)
+#ifdef CZ_ATTN_DBG
+            AST2(11);
+#endif
         }
     }
     load_v(0, pre);                                                    // first V chunk: in flight during the softmax phases

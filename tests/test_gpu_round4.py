@@ -173,3 +173,23 @@ def test_device_expf_equals_its_definition_on_every_float(cz):
     assert cz.lib().cz_debug_expf_exhaustive(out) == 0
     assert out[2] == 1 << 32
     assert out[0] == 0, "device cz_expf differs from its definition on %d inputs, the first: bits 0x%08x" % (out[0], out[1])
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 128, 64), (300, 192, 128), (129, 256, 192), (512, 576, 576), (1000, 3072, 576)])
+def test_big_gemm_half_tile_pipeline_equals_one_buffer_loop_and_oracle(cz, czo, M, N, K):
+    """round 4: the 128-row tiles of the big-M GEMM stage half K tiles (32 k, two swizzled LDS buffers) between the wave's own MFMAs (`gemm_pipe` 3, shipped) —
+    one and two K tiles (K = 64, 128: the pipeline's prologue and its last half), ragged last row tiles, both tile widths (N % 128 == 0 -> 128 x 128, else 128 x 64),
+    with and without a residual: bit for bit the one-buffer loop (`gemm_pipe` 0) and the oracle's k-ascending chain"""
+    rng = np.random.default_rng(M + N + K)
+    A = (rng.standard_normal((M, K)) * rng.choice([1e-3, 1.0, 30.0], (M, 1))).astype(np.float32)
+    W = czo.to_bf16(rng.standard_normal((N, K)) * 0.05)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    g = cz.Session("smollm", cz.tiny_llama_config(), seed=11, embed_std=0.05, max_streams=1)      # (a handle for the process-wide knob)
+    for res in (None, R):
+        ref = czo.gemm_bf16(A, W, res)
+        for pipe in (3, 0, 1, 2):
+            g.debug_set("gemm_pipe", pipe)
+            C = np.empty((M, N), np.float32)
+            assert cz.lib().cz_debug_gemm(A.ctypes.data, W.ctypes.data, res.ctypes.data if res is not None else None, C.ctypes.data, M, N, K, 1) == 0
+            assert np.array_equal(C.view(np.uint32), ref.view(np.uint32)), (pipe, res is not None)
+    g.close()

@@ -38,5 +38,5 @@ if os.environ.get("CZ_ATTN_DBG") is not None and hasattr(cz.lib(), "cz_debug_att
     nb, nc = max(o[0], 1), max(o[8], 1)
     print(json.dumps({"attention_v2_phase_cycles_per_block": {"sampled_blocks": int(o[0]), "chunks_per_block": round(nc / nb, 1), "q_and_first_k": round(o[1] / nb), "phase1_scores": round(o[2] / nb),
           "phase2_max": round(o[3] / nb), "phase3_exp_sums": round(o[4] / nb), "sums_combined": round(o[5] / nb), "phase4_p_pv": round(o[6] / nb), "stores": round(o[7] / nb),
-          "phase1_per_chunk": round(o[2] / nc), "phase3_per_chunk": round(o[4] / nc), "phase4_per_chunk": round(o[6] / nc)}}))
+          "phase1_per_chunk": round(o[2] / nc), "phase1_wait_k_registers": round(o[9] / nc), "phase1_stage_and_barrier": round(o[10] / nc), "phase1_reads_mfma_masks": round(o[11] / nc), "phase3_per_chunk": round(o[4] / nc), "phase4_per_chunk": round(o[6] / nc)}}))
 s.close()
