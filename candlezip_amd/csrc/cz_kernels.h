@@ -122,7 +122,7 @@ hipError_t cz_dec_attn_prepare(int max_nk);
 // split_scratch (cz_dec_attn_split_bytes(split_streams, n_heads) bytes, or null): scores / chunk maxima / P.V partials of the three-launch form
 // small groups take (kernels_decode.hip, "Split decode attention")
 hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nstreams, int max_nk,
-                              int n_heads, int n_kv, size_t kv_off, const int* pos_dev, int out_kq = 1, float* split_scratch = nullptr, int split_streams = 0);
+                              int n_heads, int n_kv, size_t kv_off, const int* pos_dev, int out_kq = 1, float* split_scratch = nullptr, int split_streams = 0, int concurrent_lanes = 1);
 size_t cz_dec_attn_split_bytes(int nstreams, int n_heads);
 bool cz_dec_attn_is_split(int nstreams, int max_nk, int n_heads, int n_kv, const float* split_scratch, int split_streams);
 const float* cz_dec_attn_split_partials(const float* split_scratch, int split_streams, int n_heads, int* maxc);

@@ -80,6 +80,7 @@ struct cz_session {
     double* cdf_scratch = nullptr;      // spill rows of the exact-parallel CDF kernel (cz_cdf_par_scratch_bytes)
     // decode lanes: independent lock-step groups replayed concurrently on their own HIP streams (share the weights)
     std::vector<cz_session*> lanes; bool is_lane = false; int max_lanes = 4;
+    int lanes_concurrent = 1;      // lock-step groups of the running call that decode side by side on this device (set by the lane runners; picks the decode attention's block shape)
     cz_session* fork_of = nullptr; std::vector<cz_session*> forks; bool orphan = false;   // cz_session_fork: a fork shares the parent's weights; closing the parent first orphans it (every call then fails)
     std::vector<DevBuf*> all_bufs() {   // ONE list for the constructor and cz_session_close (a buffer missing from either leaks or dangles)
         return {&tok, &x, &xn, &qkv, &gu, &h, &seqd, &roped, &rowidx, &sym, &clo, &chi, &xl, &logits, &payload, &outids, &decst, &seqd_q, &xc, &rc};

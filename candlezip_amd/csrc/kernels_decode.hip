@@ -563,7 +563,7 @@ typedef __attribute__((address_space(1))) const float gfloat;     // K/V pointer
 #define CZ_DA_OCC 4          // waves per SIMD the whole-device form is compiled for (tuning build `make da_occ6`: 6 = three blocks per CU, 80 VGPRs)
 #endif
 template <int rep, int DA_WAVES, int DA_MAXC>
-__global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : (DA_WAVES == 8 ? CZ_DA_OCC : 4))) void dec_attn_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
+__global__ __launch_bounds__(DA_WAVES * 64, (DA_WAVES * DA_MAXC > 32 ? 1 : (DA_WAVES == 8 ? CZ_DA_OCC : 4))) void dec_attn_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
                                                               const cz_seq_desc* __restrict__ descs, int n_heads, int n_kv, int s_stride,
                                                               size_t kv_off, const int* __restrict__ pos_dev, int out_kq, int kv_div) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : (DA_WAVES == 8 ? 
     float* qs = smem;                                   // [rep][64]
     float* S = qs + rep * 64;                           // [rep][s_stride]  e, then p
     constexpr bool DEEP = DA_WAVES == 16 && DA_MAXC == 2 && rep == 1;   // small grids, one block per QUERY head: every load of a chunk in flight at once (see phase 1; rep > 1 would spill under the 128-register cap of 16 waves)
-    constexpr bool LONG = DA_MAXC > 4;                   // (rounds of DA_WAVES chunk partials instead of all nch_max at once)
+    constexpr bool LONG = DA_WAVES * DA_MAXC > 32;       // contexts past 2048 keys (rounds of DA_WAVES chunk partials instead of all nch_max at once)
     constexpr int CS = DA_WAVES * DA_MAXC;               // chunks per block = stride of the chunk sums
     float* part = S + rep * s_stride;                   // [nch_max][rep][64]   chunk partials of P.V ([DA_WAVES][rep][64] per round when LONG)
     float* red = part + (LONG ? DA_WAVES : nch_max) * rep * 64;             // [DA_WAVES][DA_MAXREP] local maxima
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(DA_WAVES * 64, (DA_MAXC > 4 ? 1 : (DA_WAVES == 8 ? 
     // barriers (the bit pattern of what is loaded does not depend on them); phase 3 then starts on resident data
     // The whole-device form (two blocks per CU) requests the first 16-key round of that slab: enough to keep loads in flight through the softmax
     // phases, whose barriers otherwise leave this block's share of the memory pipe empty (CZ_DA_VPRE = 0: off)
-    constexpr int VPRE = DEEP ? 64 : ((!LONG && DA_WAVES == 8 && CZ_DA_VPRE) ? CZ_DA_VPRE_KEYS : 0);
+    constexpr int VPRE = DEEP ? 64 : ((!LONG && DA_WAVES <= 8 && CZ_DA_VPRE) ? CZ_DA_VPRE_KEYS : 0);
     float vpre[VPRE ? VPRE : 1];
     if (VPRE) {
         const int c = wave;
@@ -932,6 +932,10 @@ hipError_t cz_dec_attn_prepare(int max_nk) {
     if (e == hipSuccess) e = da_prepare<2, 8>(max_nk);
     if (e == hipSuccess) e = da_prepare<3, 8>(max_nk);
     if (e == hipSuccess) e = da_prepare<4, 8>(max_nk);
+    if (e == hipSuccess) e = da_prepare<1, 4>(max_nk);
+    if (e == hipSuccess) e = da_prepare<2, 4>(max_nk);
+    if (e == hipSuccess) e = da_prepare<3, 4>(max_nk);
+    if (e == hipSuccess) e = da_prepare<4, 4>(max_nk);
     if (e == hipSuccess) e = da_prepare<1, 16>(max_nk);
     if (e == hipSuccess) e = da_prepare<2, 16>(max_nk);
     if (e == hipSuccess) e = da_prepare<3, 16>(max_nk);
@@ -954,6 +958,11 @@ static void da_launch(hipStream_t st, int rep, dim3 grid, size_t smem, const flo
         default: hipLaunchKernelGGL((dec_attn_kernel<4, W, MC>), grid, block, smem, st, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, kv_div); break;
     }
 }
+int g_dec_attn_waves = 0;           // tuning knob (cz_debug_set "dec_attn_waves"): waves per block of the whole-device grids: 8 (each walks up to 4 chunks; two blocks per CU), 4 (up to 8
+                                    // chunks; four blocks per CU) or 0 = four where the group shares the device with other lock-step groups (lanes), eight where it runs alone.  Round 4,
+                                    // 512 streams per lane (profiles/r04_dec_attn_four_wave_blocks.txt): attention alone 2.42 / 3.47 / 4.38 ms at 511 / 767 / 1 023 keys with eight waves,
+                                    // 2.47 / 3.47 / 4.40 with four (1 536 blocks on 1 024 slots are one and a half generations); a full step alone 6.11-6.15 against 6.17-6.21; TWO lanes
+                                    // side by side 9.86-9.98 ms against **9.44-9.49**: the smaller blocks leave the other lane's projection blocks their slots sooner
 int g_dec_attn_lds_pad = 0;         // tuning knob (cz_debug_set "dec_attn_lds_pad"): extra dynamic LDS bytes per block of the whole-device grids (fewer blocks per CU)
 int g_dec_attn_split_heads = 1;     // tuning knob (cz_debug_set "dec_attn_split_heads"): 0 = never one block per query head
 // true when cz_launch_dec_attn takes the three-launch split form for this group
@@ -968,7 +977,7 @@ const float* cz_dec_attn_split_partials(const float* split_scratch, int split_st
 }
 // out_kq = -1 (split form only): the ordered sum of the chunk partials is left to the consumer (the o-projection of kernels_gemv.hip): O is not written
 hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O, int ldo, const cz_seq_desc* descs, int nstreams, int max_nk,
-                              int n_heads, int n_kv, size_t kv_off, const int* pos_dev, int out_kq, float* split_scratch, int split_streams) {
+                              int n_heads, int n_kv, size_t kv_off, const int* pos_dev, int out_kq, float* split_scratch, int split_streams, int concurrent_lanes) {
     if (nstreams <= 0) return hipSuccess;
     const int rep = n_heads / n_kv;
     if (rep < 1 || rep > DA_MAXREP || max_nk > CZ_KERNEL_MAX_CTX) return hipErrorInvalidValue;
@@ -995,6 +1004,7 @@ hipError_t cz_launch_dec_attn(hipStream_t st, const float* Q, int ldq, float* O,
     const dim3 grid(nstreams, n_kv);
     const size_t smem = da_smem(max_nk, rep);
     if (nstreams * n_kv <= g_dec_attn_small_grid) da_launch<16, 2>(st, rep, grid, smem, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, 1);
+    else if (g_dec_attn_waves == 4 || (g_dec_attn_waves == 0 && concurrent_lanes > 1)) da_launch<4, 8>(st, rep, grid, smem + (size_t)g_dec_attn_lds_pad, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, 1);
     else da_launch<8, 4>(st, rep, grid, smem + (size_t)g_dec_attn_lds_pad, Q, ldq, O, ldo, descs, n_heads, n_kv, ss, kv_off, pos_dev, out_kq, 1);
     return hipGetLastError();
 }

@@ -484,7 +484,7 @@ static cz_status llama_step_fast(cz_session* s, int B, int pos, int max_nk) {
         }
         if (!(s->dbg_skip & 1)) {
         s->prof_begin(PK_DEC_ATTN);
-        HIPCHK(cz_launch_dec_attn(st, q, d, att, d, s->step_seqd, B, max_nk, c.n_heads, c.n_kv_heads, kv_off, s->pos_dev, 1, s->attn_split, s->attn_split_streams));
+        HIPCHK(cz_launch_dec_attn(st, q, d, att, d, s->step_seqd, B, max_nk, c.n_heads, c.n_kv_heads, kv_off, s->pos_dev, 1, s->attn_split, s->attn_split_streams, s->lanes_concurrent));
         s->prof_end(4.0 * 64 * c.n_heads * (double)B * (pos + 1), 2.0 * B * (double)(pos + 1) * kvd * 4);
         }
         if (s->dbg_skip & 2) continue;
@@ -527,7 +527,7 @@ static cz_status llama_step_gemv(cz_session* s, int B, int pos, int max_nk) {
         const bool fold = g_gemv_fold_attn && !s->dbg_skip && d <= 768 && cz_dec_attn_is_split(B, max_nk, c.n_heads, c.n_kv_heads, s->attn_split, s->attn_split_streams);
         if (!(s->dbg_skip & 1)) {
             s->prof_begin(PK_DEC_ATTN);
-            HIPCHK(cz_launch_dec_attn(st, q, d, att, d, s->step_seqd, B, max_nk, c.n_heads, c.n_kv_heads, kv_off, s->pos_dev, fold ? -1 : 0, s->attn_split, s->attn_split_streams));
+            HIPCHK(cz_launch_dec_attn(st, q, d, att, d, s->step_seqd, B, max_nk, c.n_heads, c.n_kv_heads, kv_off, s->pos_dev, fold ? -1 : 0, s->attn_split, s->attn_split_streams, s->lanes_concurrent));
             s->prof_end(4.0 * 64 * c.n_heads * (double)B * (pos + 1), 2.0 * B * (double)(pos + 1) * kvd * 4);
         }
         if (s->dbg_skip & 2) continue;
@@ -594,7 +594,7 @@ static cz_status llama_step_wide(cz_session* s, int B, int pos, int max_nk) {
         }
         if (!(s->dbg_skip & 1)) {
             s->prof_begin(PK_DEC_ATTN);
-            HIPCHK(cz_launch_dec_attn(st, qkv, nq, xn, d, s->step_seqd, B, max_nk, c.n_heads, c.n_kv_heads, kv_off, s->pos_dev, hybrid ? 1 : 0, s->attn_split, s->attn_split_streams));
+            HIPCHK(cz_launch_dec_attn(st, qkv, nq, xn, d, s->step_seqd, B, max_nk, c.n_heads, c.n_kv_heads, kv_off, s->pos_dev, hybrid ? 1 : 0, s->attn_split, s->attn_split_streams, s->lanes_concurrent));
             s->prof_end(4.0 * 64 * c.n_heads * (double)B * (pos + 1), 2.0 * B * (double)(pos + 1) * kvd * 4);
         }
         if (s->dbg_skip & 2) continue;
@@ -1245,6 +1245,7 @@ static cz_status run_on_lanes(cz_session* s, size_t n_streams, GroupFn group) {
         cz_session* ls = l == 0 ? s : s->lanes[l - 1];
         if (hipSetDevice(s->device) != hipSuccess) { rc[l] = CZ_ERR_HIP; msg[l] = "hipSetDevice failed"; return; }
         if (l) lane_inherit(s, ls);
+        ls->lanes_concurrent = (int)L;
         for (size_t g = l; g < G && rc[l] == CZ_OK; g += L) {
             rc[l] = group(ls, off[g], off[g + 1] - off[g]);
             if (rc[l] != CZ_OK) msg[l] = cz_last_error();
@@ -1305,6 +1306,7 @@ static cz_status on_run_groups(cz_session* s, GroupFn group) {
         cz_session* ls = g == 0 ? s : s->lanes[g - 1];
         if (hipSetDevice(s->device) != hipSuccess) { rc[g] = CZ_ERR_HIP; msg[g] = "hipSetDevice failed"; return; }
         if (g) lane_inherit(s, ls);
+        ls->lanes_concurrent = (int)G;
         rc[g] = group(ls, g);
         if (rc[g] != CZ_OK) msg[g] = cz_last_error();
     };
@@ -1552,14 +1554,14 @@ static cz_status set_stream_priority(cz_session* s, int prio) {
 // The process-wide knobs (the g_* globals of the kernel files) with the values they are shipped with, captured the first time any knob is
 // touched: "reset_process_knobs" puts every one of them back (the tests' fixture finalizer: a test that turned one leaves no trace for
 // the tests that run after it in the same process).
-extern int g_gemv_max_rows, g_gemv_fold_attn, g_cdf_dec_grid_cap, g_gemm_lds_kb, g_gemm_pipe, g_attn_v1, g_dec_grid_target, g_dec_nw_cap, g_dec_mt_max, g_dec_norm_mfma, g_gemm_mid_rows, g_mid_nw, g_mid_colmaj, g_mid_quad,
+extern int g_gemv_max_rows, g_gemv_fold_attn, g_cdf_dec_grid_cap, g_gemm_lds_kb, g_gemm_pipe, g_dec_attn_waves, g_attn_v1, g_dec_grid_target, g_dec_nw_cap, g_dec_mt_max, g_dec_norm_mfma, g_gemm_mid_rows, g_mid_nw, g_mid_colmaj, g_mid_quad,
            g_dec_attn_split_heads, g_dec_attn_lds_pad, g_dec_wide_rows, g_dec_attn_small_grid, g_dec_attn_split_max, g_rw_seq_rows, g_rw_state_pad;
 struct ProcKnob { const char* key; int* p; int shipped; };
 static std::vector<ProcKnob>& proc_knobs() {
     static std::vector<ProcKnob> k;
     if (k.empty()) {
         const std::pair<const char*, int*> all[] = {
-            {"gemv_max_rows", &g_gemv_max_rows}, {"gemv_fold_attn", &g_gemv_fold_attn}, {"cdf_dec_grid_cap", &g_cdf_dec_grid_cap}, {"gemm_lds_kb", &g_gemm_lds_kb}, {"gemm_pipe", &g_gemm_pipe}, {"attn_v1", &g_attn_v1}, {"dec_grid_target", &g_dec_grid_target}, {"dec_nw_cap", &g_dec_nw_cap},
+            {"gemv_max_rows", &g_gemv_max_rows}, {"gemv_fold_attn", &g_gemv_fold_attn}, {"cdf_dec_grid_cap", &g_cdf_dec_grid_cap}, {"gemm_lds_kb", &g_gemm_lds_kb}, {"gemm_pipe", &g_gemm_pipe}, {"dec_attn_waves", &g_dec_attn_waves}, {"attn_v1", &g_attn_v1}, {"dec_grid_target", &g_dec_grid_target}, {"dec_nw_cap", &g_dec_nw_cap},
             {"dec_mt_max", &g_dec_mt_max}, {"dec_norm_mfma", &g_dec_norm_mfma}, {"gemm_mid_rows", &g_gemm_mid_rows}, {"mid_nw", &g_mid_nw}, {"mid_colmaj", &g_mid_colmaj},
             {"mid_quad", &g_mid_quad}, {"dec_attn_split_heads", &g_dec_attn_split_heads}, {"dec_attn_lds_pad", &g_dec_attn_lds_pad},
             {"dec_wide_rows", &g_dec_wide_rows}, {"dec_attn_small_grid", &g_dec_attn_small_grid}, {"dec_attn_split_max", &g_dec_attn_split_max},
@@ -1607,6 +1609,7 @@ extern "C" cz_status cz_debug_set(cz_session* s, const char* key, long value) {
     else if (!strcmp(key, "dec_wide_rows")) g_dec_wide_rows = (int)value;
     else if (!strcmp(key, "dec_attn_small_grid")) g_dec_attn_small_grid = (int)value;
     else if (!strcmp(key, "dec_attn_split_max")) g_dec_attn_split_max = (int)value;
+    else if (!strcmp(key, "dec_attn_waves")) g_dec_attn_waves = (int)value == 4 ? 4 : ((int)value == 8 ? 8 : 0);      // (process-wide) 0 = by the number of concurrent lanes
     else if (!strcmp(key, "gemm_pipe")) g_gemm_pipe = (int)value;        // (process-wide) 0: the 128 x 128 tiles of the big-M GEMM on the one-buffer K loop
     else if (!strcmp(key, "gemm_lds_kb")) g_gemm_lds_kb = (int)value < 0 ? 0 : ((int)value > 160 ? 160 : (int)value);   // (process-wide) fewer big-M GEMM blocks per CU
     else if (!strcmp(key, "dbg_skip")) s->dbg_skip = (int)value;          // tools/bench_decode_step.py: 1 = no attention, 2 = no GEMMs/norms (timing only; results are garbage)

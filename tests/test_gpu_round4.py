@@ -193,3 +193,25 @@ def test_big_gemm_half_tile_pipeline_equals_one_buffer_loop_and_oracle(cz, czo, 
             assert cz.lib().cz_debug_gemm(A.ctypes.data, W.ctypes.data, res.ctypes.data if res is not None else None, C.ctypes.data, M, N, K, 1) == 0
             assert np.array_equal(C.view(np.uint32), ref.view(np.uint32)), (pipe, res is not None)
     g.close()
+
+
+@pytest.mark.parametrize("waves", [4, 8, 0])
+def test_decode_attention_block_shapes_round_trip_at_long_contexts(cz, czo, waves):
+    """round 4: the whole-device decode attention with FOUR waves per block (each wave walks up to eight 64-key chunks; picked where lock-step groups share the device) against
+    eight: 150 streams of a three-query-heads-per-KV-head model decoded through the sawtooth 512 -> 1023 keys (up to sixteen chunks: two to four per wave), ragged lengths;
+    stream 0's payload against the oracle, every stream's round trip, the same ids from either shape"""
+    kw = dict(d_model=384, n_heads=6, n_kv_heads=2, d_ffn=512)
+    g = cz.Session("smollm", cz.tiny_llama_config(**kw), seed=21, embed_std=0.05, max_streams=150)
+    o = czo.SmolLmSession(czo.tiny_llama_config(**kw), seed=21, embed_std=0.05)
+    g.debug_set("dec_attn_waves", waves)
+    rng = np.random.default_rng(99)
+    lens = [1100 - 7 * (k % 11) for k in range(150)]
+    streams = [np.concatenate([[0], rng.integers(0, 512, n)]).astype(np.uint32) for n in lens]
+    pairs = g.encode_tokens_batch(streams)
+    coded = [cz.ac_encode_pairs(lo, hi) for lo, hi in pairs]
+    assert coded[0][0] == o.encode_tokens(streams[0])[0]
+    outs = g.decode_tokens_batch([p for p, _ in coded], lens)
+    for s_, out, (_, z) in zip(streams, outs, coded):
+        if z == 0:
+            assert np.array_equal(out, s_)
+    g.close(); o.close()

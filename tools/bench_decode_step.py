@@ -79,7 +79,7 @@ def main():
     parent = cz.Session("smollm", cz.smollm2_135m_config(), seed=0x5EED, embed_std=0.02, max_streams=args.max_streams)
     for c in args.configs:
         name, _, kv = c.partition(":")
-        d = dict(B=128, L=1, pos=767, x=0, av=0, fn=0, g=1, prof=0, gt=384, mt=8, wm=256, dw=256, wmode=1, nw=4, pad=0, mq=1, sp=36, av1=-1, pr0=0, pr1=0, gv=4, fa=1, ss=0)
+        d = dict(B=128, L=1, pos=767, x=0, av=0, fn=0, g=1, prof=0, gt=384, mt=8, wm=256, dw=256, wmode=1, nw=4, pad=0, mq=1, sp=36, av1=-1, pr0=0, pr1=0, gv=4, fa=1, ss=0, aw=8)
         for item in kv.split(","):
             if item:
                 k, v = item.split("=")
@@ -88,6 +88,7 @@ def main():
         STEP_SYNC[0] = d["ss"]                                                # ss=1: one host wait per step (eager runs under rocprofv3)
         WM[0] = d["wm"]; WM[1] = d["wmode"]; parent.debug_set("dec_wide_rows", d["dw"]); parent.debug_set("mid_nw", d["nw"]); parent.debug_set("dec_attn_lds_pad", d["pad"])
         parent.debug_set("gemv_max_rows", d["gv"]); parent.debug_set("gemv_fold_attn", d["fa"])      # fa: the o-projection adds up the split attention's partials
+        parent.debug_set("dec_attn_waves", d["aw"])                           # aw: waves per block of the whole-device decode attention (8, or 4: four blocks per CU)
         parent.debug_set("mid_quad", d["mq"]); parent.debug_set("dec_attn_split_max", d["sp"])     # mq: gemm_mid blocks share sum + epilogue over their waves; sp: split attention up to this many (stream, head) pairs
         run_config(parent, None, name + f"[gt={d['gt']}]", d["B"], d["L"], d["pos"], d["x"], d["av"], d["fn"], d["g"], d["prof"], args.iters, args.sym, d["av1"], d["pr0"], d["pr1"])
     parent.close()

@@ -48,6 +48,8 @@ def main():
         cfg = cz.rwkv7_0b1_config()
         s = cz.Session("rwkv7", cfg, seed=0x5EED, embed_std=0.02, max_streams=S)
     s.debug_set("max_lanes", 1); s.debug_set("no_graph", 1); s.debug_set("step_sync", 1)
+    if a.backend == "smollm":
+        s.debug_set("dec_attn_waves", 4)           # the block shape bench.py's two lanes run (one group alone would pick eight-wave blocks); --debug-set dec_attn_waves=8 for those
     for kv in a.debug_set:
         k, v = kv.split("=")
         s.debug_set(k, int(v))
