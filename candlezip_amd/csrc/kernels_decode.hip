@@ -563,7 +563,7 @@ typedef __attribute__((address_space(1))) const float gfloat;     // K/V pointer
 #define CZ_DA_OCC 4          // waves per SIMD the whole-device form is compiled for (tuning build `make da_occ6`: 6 = three blocks per CU, 80 VGPRs)
 #endif
 template <int rep, int DA_WAVES, int DA_MAXC>
-__global__ __launch_bounds__(DA_WAVES * 64, (DA_WAVES * DA_MAXC > 32 ? 1 : (DA_WAVES == 8 ? CZ_DA_OCC : 4))) void dec_attn_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
+__global__ __launch_bounds__(DA_WAVES * 64, (DA_WAVES * DA_MAXC > 32 ? 1 : (DA_WAVES <= 8 ? CZ_DA_OCC : 4))) void dec_attn_kernel(const float* __restrict__ Q, int ldq, float* __restrict__ O, int ldo,
                                                               const cz_seq_desc* __restrict__ descs, int n_heads, int n_kv, int s_stride,
                                                               size_t kv_off, const int* __restrict__ pos_dev, int out_kq, int kv_div) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
